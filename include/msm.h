@@ -1,0 +1,164 @@
+/* msm.h -- C ABI of libmsm_hip.so: the MI355X (gfx950) split-step
+ * Schroedinger-Poisson evolver that stands in for the ArrayFire calls on the
+ * hot path of andillio/MSM's `msm-simulator` crate.
+ *
+ * The reference has no FFI seam of its own on this path: every array
+ * operation of `SimulationObject::update` is an ArrayFire library call.  Each
+ * entry point below names the reference code it replaces (paths relative to
+ * the reference checkout).  A Rust binding is a plain `extern "C"` block
+ * over these signatures.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative msm_status otherwise;
+ *    nothing throws or aborts across the boundary; msm_last_error() gives text;
+ *  - one context per GPU, driven by one host thread at a time;
+ *  - host buffers are caller-owned and only touched during the call;
+ *  - a grid is N^dims values in C order, element [a][b][c] at a*N*N + b*N + c,
+ *    which is the reference's device order (simulator/src/utils/io.rs:60-68);
+ *  - "T" below is double (MSM_F64) or float (MSM_F32), chosen at create time
+ *    (the reference fixes `type T = f64`, simulator/src/main.rs:19);
+ *  - streams are the reference's independent simulations, one per seed
+ *    (simulator/src/main.rs:43-79); this library evolves many at once.
+ */
+#ifndef MSM_H
+#define MSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msm_ctx msm_ctx;
+
+enum msm_status_code {
+    MSM_OK = 0,
+    MSM_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    MSM_ERR_HIP = -2,       /* a HIP runtime call failed               */
+    MSM_ERR_NOMEM = -3,     /* device allocation failed                */
+    MSM_ERR_STATE = -4      /* call not valid in the current state     */
+};
+
+enum msm_precision { MSM_F64 = 0, MSM_F32 = 1 };
+enum msm_scheme { MSM_POISSON = 0, MSM_WIGNER = 1, MSM_HUSIMI = 2 };
+enum msm_direction { MSM_FORWARD = -1, MSM_INVERSE = 1 };
+
+/* Mirrors the fields of `SimulationParameters`
+ * (simulator/src/simulation_object.rs:67-140) that the device path needs. */
+typedef struct msm_config {
+    int32_t struct_size;        /* = sizeof(msm_config), ABI check              */
+    int32_t device;             /* HIP device ordinal (reference: set_device(0)) */
+    int32_t dims;               /* 3 (1 and 2 are not built yet)                 */
+    int32_t size;               /* N, power of two in [2, 512]                   */
+    int32_t precision;          /* msm_precision                                 */
+    int32_t n_streams;          /* streams held by this context                  */
+    int32_t batch_streams;      /* streams advanced per kernel launch; 0 = auto  */
+    int32_t expanding;          /* 0 static box, 1 cosmological (cargo feature)  */
+    double axis_length;
+    double time;                /* start time (TOML `time`, default 0)           */
+    double final_sim_time;
+    double cfl;
+    uint32_t num_data_dumps;
+    uint32_t reserved0;
+    double total_mass;
+    double particle_mass;
+    double hbar_;
+    double k2_cutoff;
+    double alias_threshold;
+    /* [cosmology] (only read when expanding != 0) */
+    double omega_matter_now;
+    double omega_radiation_now;
+    double h;
+    double z0;
+    double max_dloga;           /* <= 0: use the reference default 1e-3          */
+    void* hip_stream;           /* hipStream_t to enqueue on; NULL = own stream  */
+} msm_config;
+
+/* Per-stream result of the last step (host copy, valid after msm_sync). */
+typedef struct msm_stream_status {
+    double time;            /* simulation time after the step (snapped at dumps)  */
+    double dt;              /* timestep taken (d tau when expanding)              */
+    double max_phi;         /* max |phi| that sized the step                      */
+    double alias_mass;      /* dk^dims * sum_{k2 > cutoff k2max} |psi_k|^2        */
+    double tau;             /* supercomoving time (expanding only)                */
+    int64_t n_steps;
+    int32_t current_dumps;
+    int32_t dump;           /* 1: this step landed on a dump time                 */
+    int32_t active;         /* 0 once time >= final_sim_time or aliased           */
+    int32_t aliased;        /* 1: alias_mass > alias_threshold (reference panics) */
+} msm_stream_status;
+
+/* Library lifetime.  Replaces SimulationParameters::new + SimulationGrid::new
+ * (simulation_object.rs:203-315): derives dx, dk = dx, hbar_, the k^2 tables
+ * and k2_max, and allocates psi, psi_k and scratch for every stream. */
+int32_t msm_create(const msm_config* cfg, msm_ctx** out);
+int32_t msm_destroy(msm_ctx* ctx);
+const char* msm_last_error(const msm_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* Derived scalars, as the reference prints them with --verbose
+ * (simulation_object.rs:325-363).  out = {dx, dk, k2_max, hbar_, n_tot,
+ * kinetic_dt, comoving_boxsize(or 0)} */
+int32_t msm_get_derived(const msm_ctx* ctx, double out[8]);
+
+/* Initial conditions.
+ * msm_set_psi: upload one stream's wavefunction from two host planes of T
+ *   (what user_specified_ics builds from the npz members `real`/`imag`,
+ *   simulator/src/ics.rs:716-726, and what every IC builder ends with).
+ * msm_copy_psi: device copy stream src -> dst (every stream starts from the
+ *   same mean-field psi before sampling, simulation_object.rs:406-435).
+ * msm_sample: Wigner/Husimi Gaussian perturbation of one stream seeded by
+ *   `seed` (sample_quantum_perturbation, ics.rs:434-648).  MSM_POISSON is
+ *   rejected: the reference draws it from a non-reproducible thread RNG. */
+int32_t msm_set_psi(msm_ctx* ctx, int32_t stream, const void* re, const void* im);
+int32_t msm_copy_psi(msm_ctx* ctx, int32_t dst_stream, int32_t src_stream);
+int32_t msm_sample(msm_ctx* ctx, int32_t stream, int32_t scheme, uint64_t seed);
+
+/* Unitary FFT of one stream's psi buffer in place, scale 1/N^{dims/2} in both
+ * directions (utils/fft.rs:6-98: forward/inverse/forward_inplace/inverse_inplace). */
+int32_t msm_fft(msm_ctx* ctx, int32_t stream, int32_t direction);
+
+/* calculate_potential (simulation_object.rs:1066-1110) for streams
+ * [first, first+count): phi = Re F^-1[ -C F[M |psi|^2] / k^2 ], k = 0 mode -> 0.
+ * Also refreshes max|phi| per stream (get_timestep's max_all, :905).
+ * count must not exceed the batch size reported by msm_get_batch. */
+int32_t msm_potential(msm_ctx* ctx, int32_t first, int32_t count);
+int32_t msm_get_batch(const msm_ctx* ctx, int32_t* batch_streams);
+
+/* One SimulationObject::update (simulation_object.rs:475-661, expanding
+ * :669-873) for every active stream, asynchronous on the context's stream.
+ * Static box: msm_step does the whole update.
+ * Expanding: msm_step_begin runs the potential + timestep part (needs the
+ *   scale factor a and tau-to-next-dump per stream), the caller advances its
+ *   scale-factor solver with the returned d tau, then msm_step_end applies the
+ *   rest with kick_a[s] = a1 + a2 (the two half-kicks share phi, :726-742) and
+ *   the new (time, tau) per stream. */
+int32_t msm_step(msm_ctx* ctx);
+int32_t msm_step_begin(msm_ctx* ctx, const double* a_now, const double* tau_to_next_dump);
+int32_t msm_step_end(msm_ctx* ctx, const double* kick_a, const double* new_time, const double* new_tau,
+                     const double* snapped_tau);
+
+/* Wait for enqueued work; then status[0..n_streams) is current. */
+int32_t msm_sync(msm_ctx* ctx);
+int32_t msm_get_status(msm_ctx* ctx, msm_stream_status* out, int32_t n);
+
+/* Downloads (replace Array::host in complex_array_to_disk, utils/io.rs:46-47).
+ * psi / psi_k: two planes of T; potential: one plane of T, valid for the
+ * streams of the most recent msm_potential / step batch. */
+int32_t msm_get_psi(msm_ctx* ctx, int32_t stream, void* re, void* im);
+int32_t msm_get_psik(msm_ctx* ctx, int32_t stream, void* re, void* im);
+int32_t msm_get_potential(msm_ctx* ctx, int32_t stream, void* phi);
+
+/* sum over this context's streams of |psi_s|^2 into a DEVICE buffer of N^dims
+ * doubles (caller-owned; e.g. a torch tensor that is then all-reduced over
+ * RCCL).  In-situ form of the synthesizer's psi2 accumulation
+ * (synthesizer/src/lib.rs:217-229); it never feeds back into the evolution. */
+int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64);
+
+/* Timing helper for benchmarks: HIP events on the context's stream. */
+int32_t msm_timer_start(msm_ctx* ctx);
+int32_t msm_timer_stop_ms(msm_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libmsm_hip.so (the C ABI declared in include/msm.h).
+
+The library is the product; there is no fallback.  Importing this module
+without the built shared object raises, so that nothing silently runs on a
+CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
+
+MSM_F64, MSM_F32 = 0, 1
+MSM_POISSON, MSM_WIGNER, MSM_HUSIMI = 0, 1, 2
+MSM_FORWARD, MSM_INVERSE = -1, 1
+
+
+class MsmConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("dims", C.c_int32), ("size", C.c_int32),
+        ("precision", C.c_int32), ("n_streams", C.c_int32), ("batch_streams", C.c_int32),
+        ("expanding", C.c_int32),
+        ("axis_length", C.c_double), ("time", C.c_double), ("final_sim_time", C.c_double),
+        ("cfl", C.c_double),
+        ("num_data_dumps", C.c_uint32), ("reserved0", C.c_uint32),
+        ("total_mass", C.c_double), ("particle_mass", C.c_double), ("hbar_", C.c_double),
+        ("k2_cutoff", C.c_double), ("alias_threshold", C.c_double),
+        ("omega_matter_now", C.c_double), ("omega_radiation_now", C.c_double), ("h", C.c_double),
+        ("z0", C.c_double), ("max_dloga", C.c_double),
+        ("hip_stream", C.c_void_p),
+    ]
+
+
+class MsmStreamStatus(C.Structure):
+    _fields_ = [
+        ("time", C.c_double), ("dt", C.c_double), ("max_phi", C.c_double), ("alias_mass", C.c_double),
+        ("tau", C.c_double), ("n_steps", C.c_int64), ("current_dumps", C.c_int32), ("dump", C.c_int32),
+        ("active", C.c_int32), ("aliased", C.c_int32),
+    ]
+
+
+# every symbol include/msm.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "msm_create": (C.c_int32, [C.POINTER(MsmConfig), C.POINTER(_P)]),
+    "msm_destroy": (C.c_int32, [_P]),
+    "msm_last_error": (C.c_char_p, [_P]),
+    "msm_get_derived": (C.c_int32, [_P, C.POINTER(C.c_double)]),
+    "msm_set_psi": (C.c_int32, [_P, C.c_int32, _P, _P]),
+    "msm_copy_psi": (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    "msm_sample": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_uint64]),
+    "msm_fft": (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    "msm_potential": (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    "msm_get_batch": (C.c_int32, [_P, C.POINTER(C.c_int32)]),
+    "msm_step": (C.c_int32, [_P]),
+    "msm_step_begin": (C.c_int32, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "msm_step_end": (C.c_int32, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "msm_sync": (C.c_int32, [_P]),
+    "msm_get_status": (C.c_int32, [_P, C.POINTER(MsmStreamStatus), C.c_int32]),
+    "msm_get_psi": (C.c_int32, [_P, C.c_int32, _P, _P]),
+    "msm_get_psik": (C.c_int32, [_P, C.c_int32, _P, _P]),
+    "msm_get_potential": (C.c_int32, [_P, C.c_int32, _P]),
+    "msm_density_sum": (C.c_int32, [_P, _P]),
+    "msm_timer_start": (C.c_int32, [_P]),
+    "msm_timer_stop_ms": (C.c_int32, [_P, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmsm_hip.so and type every entry point; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is not built; run `make -C msm_amd/csrc` (or __graft_entry__.build()). "
+                "There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

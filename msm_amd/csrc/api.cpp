@@ -1,0 +1,143 @@
+// C ABI of libmsm_hip.so (declared in include/msm.h): argument checking,
+// error text and precision dispatch; all device work lives in engine.hip.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "engine.hpp"
+
+struct msm_ctx {
+    msm::IEngine* eng = nullptr;
+    std::string err;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+int fail(msm_ctx* ctx, int code, const char* what) {
+    if (ctx) ctx->err = what;
+    return code;
+}
+}  // namespace
+
+#define MSM_CHECK_CTX(ctx) \
+    if (!(ctx) || !(ctx)->eng) return MSM_ERR_INVALID
+
+extern "C" {
+
+int32_t msm_create(const msm_config* cfg, msm_ctx** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return MSM_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(msm_config)) {
+        g_create_error = "msm_config.struct_size does not match this library";
+        return MSM_ERR_INVALID;
+    }
+    if (!(cfg->hbar_ > 0.0) || !(cfg->particle_mass > 0.0) || !(cfg->axis_length > 0.0)) {
+        g_create_error = "axis_length, hbar_ and particle_mass must be positive";
+        return MSM_ERR_INVALID;
+    }
+    msm_ctx* ctx = new (std::nothrow) msm_ctx();
+    if (!ctx) { g_create_error = "out of host memory"; return MSM_ERR_NOMEM; }
+    if (cfg->precision == MSM_F64) ctx->eng = msm::make_engine_f64(*cfg);
+    else if (cfg->precision == MSM_F32) ctx->eng = msm::make_engine_f32(*cfg);
+    else { delete ctx; g_create_error = "precision must be MSM_F64 or MSM_F32"; return MSM_ERR_INVALID; }
+    const int rc = ctx->eng->init(ctx->err);
+    if (rc != MSM_OK) {
+        g_create_error = ctx->err;
+        delete ctx->eng;
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return MSM_OK;
+}
+
+int32_t msm_destroy(msm_ctx* ctx) {
+    if (!ctx) return MSM_OK;
+    delete ctx->eng;
+    delete ctx;
+    return MSM_OK;
+}
+
+const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t msm_get_derived(const msm_ctx* ctx, double out[8]) {
+    MSM_CHECK_CTX(ctx);
+    if (!out) return MSM_ERR_INVALID;
+    ctx->eng->derived(out);
+    return MSM_OK;
+}
+
+int32_t msm_set_psi(msm_ctx* ctx, int32_t stream, const void* re, const void* im) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->set_psi(stream, re, im, ctx->err);
+}
+int32_t msm_copy_psi(msm_ctx* ctx, int32_t dst_stream, int32_t src_stream) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->copy_psi(dst_stream, src_stream, ctx->err);
+}
+int32_t msm_sample(msm_ctx* ctx, int32_t stream, int32_t scheme, uint64_t seed) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->sample(stream, scheme, seed, ctx->err);
+}
+int32_t msm_fft(msm_ctx* ctx, int32_t stream, int32_t direction) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->fft(stream, direction, ctx->err);
+}
+int32_t msm_potential(msm_ctx* ctx, int32_t first, int32_t count) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->potential(first, count, ctx->err);
+}
+int32_t msm_get_batch(const msm_ctx* ctx, int32_t* batch_streams) {
+    MSM_CHECK_CTX(ctx);
+    if (!batch_streams) return MSM_ERR_INVALID;
+    *batch_streams = ctx->eng->batch();
+    return MSM_OK;
+}
+int32_t msm_step(msm_ctx* ctx) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->step(ctx->err);
+}
+int32_t msm_step_begin(msm_ctx* ctx, const double* a_now, const double* tau_to_next_dump) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->step_begin(a_now, tau_to_next_dump, ctx->err);
+}
+int32_t msm_step_end(msm_ctx* ctx, const double* kick_a, const double* new_time, const double* new_tau,
+                     const double* snapped_tau) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->step_end(kick_a, new_time, new_tau, snapped_tau, ctx->err);
+}
+int32_t msm_sync(msm_ctx* ctx) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->sync(ctx->err);
+}
+int32_t msm_get_status(msm_ctx* ctx, msm_stream_status* out, int32_t n) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->get_status(out, n, ctx->err);
+}
+int32_t msm_get_psi(msm_ctx* ctx, int32_t stream, void* re, void* im) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->get_psi(stream, re, im, false, ctx->err);
+}
+int32_t msm_get_psik(msm_ctx* ctx, int32_t stream, void* re, void* im) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->get_psi(stream, re, im, true, ctx->err);
+}
+int32_t msm_get_potential(msm_ctx* ctx, int32_t stream, void* phi) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->get_potential(stream, phi, ctx->err);
+}
+int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->density_sum(device_out_f64, ctx->err);
+}
+int32_t msm_timer_start(msm_ctx* ctx) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->timer_start(ctx->err);
+}
+int32_t msm_timer_stop_ms(msm_ctx* ctx, float* ms) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->timer_stop(ms, ctx->err);
+}
+
+}  // extern "C"

@@ -1,0 +1,1081 @@
+// Split-step Schroedinger-Poisson engine for gfx950, one real type per
+// translation unit (-DMSM_REAL=double|float -DMSM_SUFFIX=f64|f32).
+//
+// Device layout (per context):
+//   X[n_streams][N^3]  complex  psi   (real space)       simulation_object.rs:57
+//   K[n_streams][N^3]  complex  psi_k (Fourier space)    simulation_object.rs:60
+//   W[batch/2][N^3]    complex  Poisson work array: two streams' densities
+//                               packed as re/im of one complex grid
+//   PHI[batch][N^3]    real     potential per stream     simulation_object.rs:63
+// A 3-D transform is three passes of the batched line FFT (fft_core.hpp), one
+// per axis, each moving every element once HBM -> registers -> HBM; all
+// pointwise operators of the step are applied inside a pass's load or store.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "engine.hpp"
+#include "fft_core.hpp"
+
+#ifndef MSM_REAL
+#define MSM_REAL double
+#endif
+
+namespace msm {
+namespace {
+
+using real = MSM_REAL;
+using cplx = cx<real>;
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            err = std::string(#expr) + ": " + hipGetErrorString(e__);              \
+            return e__ == hipErrorOutOfMemory ? MSM_ERR_NOMEM : MSM_ERR_HIP;       \
+        }                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// device-side per-stream state (structure of arrays) and step constants
+// ---------------------------------------------------------------------------
+struct State {
+    real* time;
+    real* tau;
+    real* dt;
+    real* kick;                     // phase per unit phi of the kick: -dt/hbar_ (static)
+    real* a_now;                    // expanding: scale factor at step start
+    real* tau_next;                 // expanding: tau to next dump
+    unsigned long long* maxphi;     // bits of (double) max|phi|, >= 0
+    double* alias_sum;
+    int* active;
+    int* dump;
+    int* dumps;
+    int* aliased;
+    long long* nsteps;
+    cplx* drift;                    // [n_streams][N] exp(i c k_i^2 (2 pi)^2)
+    msm_stream_status* status;      // [n_streams]
+};
+
+struct Consts {
+    real cfl, box, hbar, k2max, tfinal, dkpow, alias_thr, alias_cut, mass_factor, pois_c, fourpi2;
+    real inv_n3;      // 1 / N^dims : forward and inverse unitary scales combined
+    real unit_scale;  // 1 / N^(dims/2)
+    int ndumps, expanding, N, dims;
+};
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
+
+template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    return red[0];
+}
+template <int THREADS>
+__device__ __forceinline__ double block_max(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = THREADS / 2; off > 0; off >>= 1) {
+        // NaN must win so that a poisoned potential is visible to the host
+        if (tid < off) {
+            double a = red[tid], b = red[tid + off];
+            red[tid] = (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+        }
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// Tile geometry shared by all pass kernels.  AX = 0: lines along x (unit
+// stride); 1: along y (stride N); 2: along z (stride N^2).  c1/c2 are the two
+// coordinates that are constant along the line, in (x,y,z) order with the pass
+// axis removed.
+template <int N, int AX>
+struct Tile {
+    using G = Geom<N>;
+    int ln, j0, c1, c2;
+    size_t base, stride;
+    __device__ __forceinline__ Tile(int tile, int tid) {
+        constexpr int LPW = G::LPW, TPL = G::TPL;
+        if constexpr (AX == 0) {
+            j0 = tid % TPL;
+            ln = tid / TPL;
+            const int line = tile * LPW + ln;
+            base = (size_t)line * N;
+            stride = 1;
+            c1 = line % N;  // y
+            c2 = line / N;  // z
+        } else if constexpr (AX == 1) {
+            ln = tid % LPW;
+            j0 = tid / LPW;
+            constexpr int TPP = N / LPW;
+            const int z = tile / TPP;
+            const int x = (tile % TPP) * LPW + ln;
+            base = (size_t)z * N * N + x;
+            stride = N;
+            c1 = x;
+            c2 = z;
+        } else {
+            ln = tid % LPW;
+            j0 = tid / LPW;
+            const int m = tile * LPW + ln;
+            base = (size_t)m;
+            stride = (size_t)N * N;
+            c1 = m % N;  // x
+            c2 = m / N;  // y
+        }
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
+    using G = Geom<N>;
+    if constexpr (G::USES_LDS) {
+        for (int i = threadIdx.x; i < N; i += G::THREADS) tw_lds[i] = tw_g[i];
+        // visibility: the first use is after the stage-0 exchange barrier
+    }
+}
+
+// ---------------------------------------------------------------------------
+// psi passes: every transform of psi / psi_k and the plain passes on W
+// ---------------------------------------------------------------------------
+struct PsiArgs {
+    const cplx* src;
+    cplx* dst;
+    size_t n3;
+    const int* active;   // may be null
+    int s0;              // first stream of this launch
+    int pair_nb;         // > 0: blockIdx.y is a PAIR index over nb streams (W passes)
+    const cplx* tw;
+    const cplx* drift;
+    const real* phi;     // [batch][n3], local stream index
+    const real* kick;
+    real scale;
+    double* alias_sum;
+    const real* ksq;
+    real alias_cut, fourpi2;
+};
+
+// LOAD: 0 plain, 1 multiply by the drift table at the line position,
+//       2 kick psi *= exp(i kick phi)       (simulation_object.rs:535-545)
+// STORE: 0 scale only, 1 drift table times scale (simulation_object.rs:562-574),
+//        2 as 1 plus the aliased-mass sum     (simulation_object.rs:1249-1280)
+template <int N, int SGN, int AX, int LOAD, int STORE>
+__global__ __launch_bounds__(Geom<N>::THREADS) void k_psi_pass(PsiArgs a) {
+    using G = Geom<N>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+    __shared__ double red[STORE == 2 ? G::THREADS : 1];
+
+    const int ls = blockIdx.y;
+    int s = a.s0 + ls;
+    if (a.pair_nb > 0) {
+        const int sa = a.s0 + 2 * ls, sb = sa + 1;
+        const bool act = a.active == nullptr || a.active[sa] || (2 * ls + 1 < a.pair_nb && a.active[sb]);
+        if (!act) return;
+        s = ls;  // W is indexed by the local pair
+    } else if (a.active != nullptr && !a.active[s]) {
+        return;
+    }
+    const int sg = a.s0 + ls;  // global stream id for per-stream tables
+
+    const Tile<N, AX> t(blockIdx.x, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+
+    const cplx* __restrict__ src = a.src + (size_t)s * a.n3;
+    cplx* __restrict__ dst = a.dst + (size_t)s * a.n3;
+
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = src[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
+
+    if constexpr (LOAD == 1) {
+        const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+    } else if constexpr (LOAD == 2) {
+        const real* __restrict__ phi = a.phi + (size_t)ls * a.n3;
+        const real kc = a.kick[sg];
+        real ph[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) ph[q] = phi[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            real sn, cs;
+            sincos_t(kc * ph[q], &sn, &cs);
+            v[q] = cmul(v[q], mk<real>(cs, sn));
+        }
+    }
+
+    LineFft<real, N, SGN>::run(v, t.j0, line, tw);
+
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int pos = t.j0 + TPL * q;
+        cplx val = v[q];
+        if constexpr (STORE >= 1) val = cmul(val, a.drift[(size_t)sg * N + pos]);
+        val = cscale(val, a.scale);
+        dst[t.base + (size_t)pos * t.stride] = val;
+        if constexpr (STORE == 2) {
+            // k^2 in the reference's association ((kx^2 + ky^2) + kz^2) * (2 pi)^2
+            real k2;
+            if constexpr (AX == 2) k2 = ((a.ksq[t.c1] + a.ksq[t.c2]) + a.ksq[pos]) * a.fourpi2;
+            else if constexpr (AX == 1) k2 = ((a.ksq[t.c1] + a.ksq[pos]) + a.ksq[t.c2]) * a.fourpi2;
+            else k2 = ((a.ksq[pos] + a.ksq[t.c1]) + a.ksq[t.c2]) * a.fourpi2;
+            if (k2 > a.alias_cut) acc += (double)(val.x * val.x + val.y * val.y);
+        }
+    }
+    if constexpr (STORE == 2) {
+        const double tot = block_sum<G::THREADS>(acc, red);
+        if (threadIdx.x == 0) atomicAdd(&a.alias_sum[sg], tot);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Poisson solve (calculate_potential, simulation_object.rs:1066-1110) on
+// stream pairs: rho_a + i rho_b is transformed as one complex grid; the
+// Green's function is real and even, so the inverse returns phi_a + i phi_b.
+// ---------------------------------------------------------------------------
+struct PoisArgs {
+    const cplx* X;       // [n_streams][n3]
+    cplx* W;             // [pairs][n3]
+    real* PHI;           // [batch][n3]
+    size_t n3;
+    const int* active;
+    int s0, nb;
+    const cplx* tw;
+    const real* ksq;
+    real mass_factor, pois_c, fourpi2, inv_n3;
+    unsigned long long* maxphi;
+};
+
+// x-pass, forward: load rho = M |psi|^2 of both streams of the pair
+// (calculate_density, simulation_object.rs:1031-1063).
+template <int N>
+__global__ __launch_bounds__(Geom<N>::THREADS) void k_rho_pass(PoisArgs a) {
+    using G = Geom<N>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool has_b = (2 * p + 1 < a.nb);
+    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
+
+    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+
+    const cplx* __restrict__ xa = a.X + (size_t)sa * a.n3;
+    const cplx* __restrict__ xb = a.X + (size_t)sb * a.n3;
+    cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+
+    cplx v[E];
+    if (has_b) {
+        cplx va[E], vb[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            va[q] = xa[t.base + t.j0 + TPL * q];
+            vb[q] = xb[t.base + t.j0 + TPL * q];
+        }
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            v[q] = mk<real>(a.mass_factor * (va[q].x * va[q].x + va[q].y * va[q].y),
+                            a.mass_factor * (vb[q].x * vb[q].x + vb[q].y * vb[q].y));
+    } else {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const cplx va = xa[t.base + t.j0 + TPL * q];
+            v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), (real)0);
+        }
+    }
+    LineFft<real, N, -1>::run(v, t.j0, line, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
+}
+
+// z-pass, fused: forward FFT, Green's multiply -C / k^2 with the k = 0 mode
+// zeroed (simulation_object.rs:1076-1102), inverse FFT.  The unitary scales of
+// both 3-D transforms (1/N^3 in total, exact) ride on the Green's factor.
+template <int N>
+__global__ __launch_bounds__(Geom<N>::THREADS) void k_poisson_mid(PoisArgs a) {
+    using G = Geom<N>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
+
+    const Tile<N, 2> t(blockIdx.x, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+    cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = w[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
+    LineFft<real, N, -1>::run(v, t.j0, line, tw);
+
+    const real kxy = a.ksq[t.c1] + a.ksq[t.c2];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const real k2 = (kxy + a.ksq[t.j0 + TPL * q]) * a.fourpi2;
+        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c / k2) * a.inv_n3;
+        v[q] = cscale(v[q], g);
+    }
+    if constexpr (G::USES_LDS) __syncthreads();  // all exchange reads of the forward run are done
+    LineFft<real, N, +1>::run(v, t.j0, line, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) w[t.base + (size_t)(t.j0 + TPL * q) * t.stride] = v[q];
+}
+
+// x-pass, inverse: split phi_a / phi_b, track max|phi| per stream
+// (real(phi) simulation_object.rs:1109; max_all(abs(phi)) :905).
+template <int N, int STOREPHI>
+__global__ __launch_bounds__(Geom<N>::THREADS) void k_phi_out(PoisArgs a) {
+    using G = Geom<N>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+    __shared__ double red[G::THREADS];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool has_b = (2 * p + 1 < a.nb);
+    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
+
+    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+    const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = w[t.base + t.j0 + TPL * q];
+    LineFft<real, N, +1>::run(v, t.j0, line, tw);
+
+    real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
+    real* __restrict__ pb = a.PHI + (size_t)(2 * p + 1) * a.n3;
+    double ma = 0.0, mb = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const size_t g = t.base + t.j0 + TPL * q;
+        if constexpr (STOREPHI) {
+            pa[g] = v[q].x;
+            if (has_b) pb[g] = v[q].y;
+        }
+        const double ax = fabs((double)v[q].x), ay = fabs((double)v[q].y);
+        ma = (ax != ax) ? ax : ((ma != ma) ? ma : (ax > ma ? ax : ma));
+        mb = (ay != ay) ? ay : ((mb != mb) ? mb : (ay > mb ? ay : mb));
+    }
+    const double ra = block_max<G::THREADS>(ma, red);
+    __syncthreads();
+    const double rb = block_max<G::THREADS>(mb, red);
+    if (threadIdx.x == 0) {
+        // non-negative doubles (and NaN, which sorts above them) order like their bit patterns
+        atomicMax(&a.maxphi[sa], (unsigned long long)__double_as_longlong(ra));
+        if (has_b) atomicMax(&a.maxphi[sb], (unsigned long long)__double_as_longlong(rb));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scalar kernels: one thread per stream, arithmetic order of the reference
+// ---------------------------------------------------------------------------
+__global__ void k_zero_reductions(State st, int s0, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) {
+        st.maxphi[s0 + i] = 0ull;
+        st.alias_sum[s0 + i] = 0.0;
+    }
+}
+
+// get_timestep (simulation_object.rs:878-934; expanding :939-990)
+__global__ void k_timestep(State st, Consts c, int s0, int nb) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int s = s0 + i;
+    if (!st.active[s]) return;
+    const real pmax = (real)__longlong_as_double((long long)st.maxphi[s]);
+    const real two = (real)2.0, twopi = (real)(2.0 * 3.14159265358979323846);
+    real kinetic, potential, ttnd;
+    if (c.expanding) {
+        kinetic = c.cfl * two * c.box / sqrt(c.k2max);
+        potential = c.cfl * twopi / ((real)(2.0 * (double)st.a_now[s]) * pmax);
+        ttnd = st.tau_next[s];
+    } else {
+        kinetic = c.cfl * two * c.box / sqrt(c.k2max) / c.hbar;
+        potential = c.cfl * twopi * c.hbar / (two * pmax);
+        ttnd = (real)(st.dumps[s] + 1) * c.tfinal / (real)c.ndumps - st.time[s];
+    }
+    real dt = fmin(fmin(kinetic, potential), ttnd);
+    st.dt[s] = dt;
+    st.dump[s] = (dt == ttnd) ? 1 : 0;
+    if (!c.expanding) st.kick[s] = -dt / c.hbar;
+}
+
+// kinetic half-drift table exp(i c k_i^2 (2 pi)^2), c = -dt/4 * hbar_
+// (simulation_object.rs:504-516; expanding c = -dtau/4, :699-708).  The k-phase
+// is separable over the axes, so each pass multiplies by one 1-D factor.
+// Evaluated in double for both precisions.
+__global__ void k_drift_table(State st, Consts c, const real* __restrict__ ksq, int s0) {
+    const int s = s0 + blockIdx.y;
+    if (!st.active[s]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.N) return;
+    real coef;
+    {
+#pragma clang fp contract(off)
+        const real dt = st.dt[s];
+        coef = c.expanding ? (-dt / (real)4.0) : (-dt / (real)4.0 * c.hbar);
+    }
+    const real k2 = ksq[i] * c.fourpi2;
+    double sn, cs;
+    sincos((double)coef * (double)k2, &sn, &cs);
+    st.drift[(size_t)s * c.N + i] = mk<real>((real)cs, (real)sn);
+}
+
+// tail of update (simulation_object.rs:589-635; expanding :757-759,:814-844)
+__global__ void k_post_step(State st, Consts c, int s0, int nb, const real* new_time, const real* new_tau,
+                            const real* snapped_tau) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int s = s0 + i;
+    if (!st.active[s]) return;
+    if (c.expanding) {
+        st.time[s] = new_time[s];
+        st.tau[s] = new_tau[s];
+    } else {
+        st.time[s] = st.time[s] + st.dt[s];
+    }
+    const real p_mass = (real)st.alias_sum[s] * c.dkpow;
+    const bool aliased = p_mass > c.alias_thr;
+    st.aliased[s] = aliased ? 1 : 0;
+    if (!aliased && st.dump[s]) {
+        st.dumps[s] += 1;
+        st.time[s] = (real)st.dumps[s] * c.tfinal / (real)c.ndumps;
+        if (c.expanding) st.tau[s] = snapped_tau[s];
+    }
+    st.nsteps[s] += 1;
+    st.active[s] = (!aliased && st.time[s] < c.tfinal) ? 1 : 0;
+}
+
+__global__ void k_publish(State st, Consts c, int ns) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    msm_stream_status o;
+    o.time = (double)st.time[s];
+    o.dt = (double)st.dt[s];
+    o.max_phi = __longlong_as_double((long long)st.maxphi[s]);
+    o.alias_mass = (double)((real)st.alias_sum[s] * c.dkpow);
+    o.tau = (double)st.tau[s];
+    o.n_steps = st.nsteps[s];
+    o.current_dumps = st.dumps[s];
+    o.dump = st.dump[s];
+    o.active = st.active[s];
+    o.aliased = st.aliased[s];
+    st.status[s] = o;
+}
+
+// ---------------------------------------------------------------------------
+// initial-condition helpers
+// ---------------------------------------------------------------------------
+__global__ void k_interleave(cplx* __restrict__ dst, const real* __restrict__ re, const real* __restrict__ im, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = mk<real>(re[i], im[i]);
+}
+__global__ void k_split(const cplx* __restrict__ src, real* __restrict__ re, real* __restrict__ im, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const cplx v = src[i];
+        re[i] = v.x;
+        im[i] = v.y;
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Wigner / Husimi perturbation (sample_quantum_perturbation, ics.rs:560-646):
+// psi <- (psi sqrt(dV) + (N1 + i N2) / div) / sqrt(dV).  Element e draws its
+// pair from Philox4x32-10 counter (e_lo, e_hi, 0, 0), key = seed, Box-Muller in
+// double.  (ArrayFire's own normal stream is not reproducible from the
+// reference tree; statistics, not bits, are what carries over.)
+__global__ void k_sample(cplx* __restrict__ psi, size_t n, unsigned long long seed, real sqrt_dv, real div) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        unsigned r[4];
+        philox4x32_10((unsigned)(e & 0xffffffffu), (unsigned)(e >> 32), 0u, 0u, (unsigned)(seed & 0xffffffffu),
+                      (unsigned)(seed >> 32), r);
+        const unsigned long long b1 = (((unsigned long long)r[1] << 32) | r[0]) >> 11;
+        const unsigned long long b2 = (((unsigned long long)r[3] << 32) | r[2]) >> 11;
+        const double u1 = ((double)b1 + 0.5) * 0x1.0p-53, u2 = ((double)b2 + 0.5) * 0x1.0p-53;
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(2.0 * 3.14159265358979323846 * u2, &sn, &cs);
+        const cplx z = mk<real>((real)(rad * cs), (real)(rad * sn));
+        cplx v = psi[e];
+        v = mk<real>(v.x * sqrt_dv, v.y * sqrt_dv);
+        v = mk<real>(v.x + z.x / div, v.y + z.y / div);
+        psi[e] = mk<real>(v.x / sqrt_dv, v.y / sqrt_dv);
+    }
+}
+
+// sum over streams of |psi_s|^2 (double accumulation)
+__global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, double* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (size_t)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int s = 0; s < ns; ++s) {
+            const cplx v = X[(size_t)s * n3 + i];
+            acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        }
+        out[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// size dispatch
+// ---------------------------------------------------------------------------
+template <typename F>
+bool dispatch_n(int N, F&& f) {
+    switch (N) {
+        case 2: f(std::integral_constant<int, 2>{}); return true;
+        case 4: f(std::integral_constant<int, 4>{}); return true;
+        case 8: f(std::integral_constant<int, 8>{}); return true;
+        case 16: f(std::integral_constant<int, 16>{}); return true;
+        case 32: f(std::integral_constant<int, 32>{}); return true;
+        case 64: f(std::integral_constant<int, 64>{}); return true;
+        case 128: f(std::integral_constant<int, 128>{}); return true;
+        case 256: f(std::integral_constant<int, 256>{}); return true;
+        case 512: f(std::integral_constant<int, 512>{}); return true;
+        default: return false;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the engine
+// ---------------------------------------------------------------------------
+class Engine final : public IEngine {
+  public:
+    explicit Engine(const msm_config& cfg) : cfg_(cfg) {}
+    ~Engine() override { release(); }
+
+    int init(std::string& err) override;
+    int set_psi(int s, const void* re, const void* im, std::string& err) override;
+    int copy_psi(int dst, int src, std::string& err) override;
+    int sample(int s, int scheme, uint64_t seed, std::string& err) override;
+    int fft(int s, int dir, std::string& err) override;
+    int potential(int first, int count, std::string& err) override;
+    int step(std::string& err) override;
+    int step_begin(const double* a_now, const double* tau_next, std::string& err) override;
+    int step_end(const double* kick_a, const double* new_time, const double* new_tau, const double* snapped_tau,
+                 std::string& err) override;
+    int sync(std::string& err) override;
+    int get_status(msm_stream_status* out, int n, std::string& err) override;
+    int get_psi(int s, void* re, void* im, bool kspace, std::string& err) override;
+    int get_potential(int s, void* phi, std::string& err) override;
+    int density_sum(void* dev_out, std::string& err) override;
+    int timer_start(std::string& err) override;
+    int timer_stop(float* ms, std::string& err) override;
+    void derived(double out[8]) const override {
+        out[0] = (double)dx_; out[1] = (double)dx_; out[2] = (double)c_.k2max; out[3] = (double)c_.hbar;
+        out[4] = cfg_.total_mass / cfg_.particle_mass;
+        out[5] = (double)kinetic_dt_; out[6] = (double)comoving_box_; out[7] = 0.0;
+    }
+    int batch() const override { return batch_; }
+
+  private:
+    void release();
+    int check_stream(int s, std::string& err) const {
+        if (s < 0 || s >= ns_) { err = "stream index out of range"; return MSM_ERR_INVALID; }
+        return MSM_OK;
+    }
+    // one axis pass of a psi-type transform
+    template <int SGN, int LOAD, int STORE>
+    void launch_psi(int ax, const PsiArgs& a, int nblk_y);
+    // whole 3-D transforms
+    void fft3_plain(cplx* src, cplx* dst, int s0, int n, int sgn, const int* active);
+    void poisson(int s0, int nb, bool store_phi);
+    void step_front(int s0, int nb);
+    void step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
+    void ensure_kspace(int s0, int nb);
+    void publish();
+
+    msm_config cfg_;
+    int N_ = 0, ns_ = 0, batch_ = 0, dims_ = 3;
+    size_t n3_ = 0;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    cplx *X_ = nullptr, *K_ = nullptr, *W_ = nullptr, *tw_ = nullptr;
+    real *PHI_ = nullptr, *ksq_ = nullptr;
+    real *d_in_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // expanding per-step inputs
+    State st_{};
+    Consts c_{};
+    real dx_ = 0, kinetic_dt_ = 0, comoving_box_ = 0;
+    msm_stream_status* h_status_ = nullptr;
+    std::vector<int> host_active_;
+    bool kspace_valid_ = false;
+    bool in_step_ = false;
+    int phi_s0_ = -1, phi_nb_ = 0;
+    std::vector<void*> allocs_;
+};
+
+void Engine::release() {
+    for (void* p : allocs_) (void)hipFree(p);
+    allocs_.clear();
+    if (h_status_) (void)hipHostFree(h_status_);
+    h_status_ = nullptr;
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
+}
+
+int Engine::init(std::string& err) {
+    N_ = cfg_.size;
+    ns_ = cfg_.n_streams;
+    dims_ = cfg_.dims;
+    if (dims_ != 3) { err = "only dims = 3 is built"; return MSM_ERR_INVALID; }
+    if (N_ < 2 || N_ > 512 || (N_ & (N_ - 1))) { err = "size must be a power of two in [2, 512]"; return MSM_ERR_INVALID; }
+    if (ns_ < 1) { err = "n_streams must be >= 1"; return MSM_ERR_INVALID; }
+    if (cfg_.num_data_dumps == 0) { err = "num_data_dumps must be >= 1"; return MSM_ERR_INVALID; }
+    n3_ = (size_t)N_ * N_ * N_;
+
+    HIP_TRY(hipSetDevice(cfg_.device));
+    if (cfg_.hip_stream) {
+        stream_ = (hipStream_t)cfg_.hip_stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        own_stream_ = true;
+    }
+    HIP_TRY(hipEventCreate(&ev0_));
+    HIP_TRY(hipEventCreate(&ev1_));
+
+    // sub-batch: bounded scratch (W + PHI = 2 real grids per stream), even count
+    batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
+    if (batch_ > ns_) batch_ = ns_;
+    if (batch_ > 1 && (batch_ & 1)) batch_ -= 1;
+
+    // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
+    const real L = (real)cfg_.axis_length;
+    const real hbar = (real)cfg_.hbar_;
+    real box = L;
+    if (cfg_.expanding) {
+        const double a0 = 1.0 / (1.0 + cfg_.z0);
+        const double comoving = cfg_.axis_length / a0;
+        const double hh = 1.022e-4 * cfg_.h;
+        comoving_box_ = (real)(std::sqrt(std::sqrt(1.5 * cfg_.omega_matter_now * hh * hh) / (double)hbar) * comoving);
+        box = comoving_box_;
+    }
+    dx_ = box / (real)N_;
+    std::vector<real> ksq(N_);
+    for (int i = 0; i < N_; ++i) {
+        const int ii = i < N_ / 2 ? i : i - N_;
+        const real k = (real)ii / ((real)N_ * dx_);   // get_kgrid, utils/fft.rs:100-120
+        ksq[i] = k * k;
+    }
+    const real fourpi2 = std::pow((real)(2.0 * M_PI), (real)2.0);  // utils/fft.rs:154-160
+    const real km = ksq[N_ / 2];
+    c_.k2max = ((km + km) + km) * fourpi2;
+    c_.cfl = (real)cfg_.cfl;
+    c_.box = box;
+    c_.hbar = hbar;
+    c_.tfinal = (real)cfg_.final_sim_time;
+    c_.ndumps = (int)cfg_.num_data_dumps;
+    c_.dkpow = std::pow(dx_, (real)dims_);                         // dk = dx, :263, :1281-1285
+    c_.alias_thr = (real)cfg_.alias_threshold;
+    c_.alias_cut = c_.k2max * (real)cfg_.k2_cutoff;                // :1265
+    c_.fourpi2 = fourpi2;
+    c_.expanding = cfg_.expanding ? 1 : 0;
+    c_.N = N_;
+    c_.dims = dims_;
+    const double pois_const = 4.0 * M_PI * 4.49e-12;               // common/src/constants.rs:2
+    if (cfg_.expanding) {
+        const double hh = cfg_.h * 1.022e-4;
+        const real f = (real)(cfg_.total_mass * pois_const * std::pow(2.0 / (3.0 * hh * hh * cfg_.omega_matter_now), 0.25));
+        c_.mass_factor = f / std::pow(hbar, (real)(dims_ / 2.0));  // :1033-1048
+        c_.pois_c = (real)-1.0;
+        kinetic_dt_ = c_.cfl * (real)2.0 * box / std::sqrt(c_.k2max);
+    } else {
+        c_.mass_factor = (real)cfg_.total_mass;
+        c_.pois_c = (real)(-pois_const);
+        kinetic_dt_ = c_.cfl * (real)2.0 * box / std::sqrt(c_.k2max) / hbar;
+    }
+    c_.inv_n3 = (real)(1.0 / ((double)N_ * N_ * N_));
+    c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
+
+    // ---- device memory
+    auto dmalloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) allocs_.push_back(*p);
+        return e;
+    };
+    const size_t grid_bytes = n3_ * sizeof(cplx);
+    HIP_TRY(dmalloc((void**)&X_, grid_bytes * ns_));
+    HIP_TRY(dmalloc((void**)&K_, grid_bytes * ns_));
+    const int pairs = (batch_ + 1) / 2;
+    HIP_TRY(dmalloc((void**)&W_, grid_bytes * pairs));
+    HIP_TRY(dmalloc((void**)&PHI_, n3_ * sizeof(real) * (size_t)(2 * pairs)));
+    HIP_TRY(dmalloc((void**)&tw_, sizeof(cplx) * N_));
+    HIP_TRY(dmalloc((void**)&ksq_, sizeof(real) * N_));
+    HIP_TRY(dmalloc((void**)&st_.time, sizeof(real) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.tau, sizeof(real) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.dt, sizeof(real) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.kick, sizeof(real) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.a_now, sizeof(real) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.tau_next, sizeof(real) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.maxphi, sizeof(unsigned long long) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.alias_sum, sizeof(double) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.active, sizeof(int) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.dump, sizeof(int) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.dumps, sizeof(int) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.aliased, sizeof(int) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.nsteps, sizeof(long long) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.drift, sizeof(cplx) * (size_t)ns_ * N_));
+    HIP_TRY(dmalloc((void**)&st_.status, sizeof(msm_stream_status) * ns_));
+    for (int i = 0; i < 3; ++i) HIP_TRY(dmalloc((void**)&d_in_[i], sizeof(real) * ns_));
+    HIP_TRY(hipHostMalloc((void**)&h_status_, sizeof(msm_stream_status) * ns_));
+
+    // ---- tables
+    std::vector<cplx> tw(N_);
+    for (int p = 0; p < N_; ++p) {
+        const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)p / (long double)N_;
+        tw[p].x = (real)cosl(ang);
+        tw[p].y = (real)sinl(ang);
+    }
+    HIP_TRY(hipMemcpy(tw_, tw.data(), sizeof(cplx) * N_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ksq_, ksq.data(), sizeof(real) * N_, hipMemcpyHostToDevice));
+
+    // ---- per-stream state
+    std::vector<real> t0(ns_, (real)cfg_.time), zr(ns_, (real)0);
+    std::vector<int> ones(ns_, 1), zi(ns_, 0);
+    std::vector<long long> zl(ns_, 0);
+    std::vector<cplx> one_c((size_t)ns_ * N_);
+    for (auto& v : one_c) { v.x = (real)1; v.y = (real)0; }
+    HIP_TRY(hipMemcpy(st_.time, t0.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.tau, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.dt, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.kick, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.a_now, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.tau_next, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(st_.maxphi, 0, sizeof(unsigned long long) * ns_));
+    HIP_TRY(hipMemset(st_.alias_sum, 0, sizeof(double) * ns_));
+    HIP_TRY(hipMemcpy(st_.active, ones.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.dump, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.dumps, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.aliased, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.nsteps, zl.data(), sizeof(long long) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.drift, one_c.data(), sizeof(cplx) * (size_t)ns_ * N_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(X_, 0, grid_bytes * ns_));
+    HIP_TRY(hipMemset(K_, 0, grid_bytes * ns_));
+    host_active_.assign(ns_, 1);
+    publish();
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return MSM_OK;
+}
+
+void Engine::publish() {
+    k_publish<<<(ns_ + 63) / 64, 64, 0, stream_>>>(st_, c_, ns_);
+    (void)hipMemcpyAsync(h_status_, st_.status, sizeof(msm_stream_status) * ns_, hipMemcpyDeviceToHost, stream_);
+}
+
+template <int SGN, int LOAD, int STORE>
+void Engine::launch_psi(int ax, const PsiArgs& a, int nblk_y) {
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using G = Geom<N>;
+        const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)nblk_y);
+        const dim3 block(G::THREADS);
+        if (ax == 0) k_psi_pass<N, SGN, 0, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+        else if (ax == 1) k_psi_pass<N, SGN, 1, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+        else k_psi_pass<N, SGN, 2, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+    });
+}
+
+// unitary 3-D transform without pointwise work: first pass src -> dst, rest in place
+void Engine::fft3_plain(cplx* src, cplx* dst, int s0, int n, int sgn, const int* active) {
+    PsiArgs a{};
+    a.n3 = n3_; a.active = active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.scale = (real)1;
+    if (sgn < 0) {
+        a.src = src; a.dst = dst; launch_psi<-1, 0, 0>(0, a, n);
+        a.src = dst;              launch_psi<-1, 0, 0>(1, a, n);
+        a.scale = c_.unit_scale;  launch_psi<-1, 0, 0>(2, a, n);
+    } else {
+        a.src = src; a.dst = dst; launch_psi<+1, 0, 0>(2, a, n);
+        a.src = dst;              launch_psi<+1, 0, 0>(1, a, n);
+        a.scale = c_.unit_scale;  launch_psi<+1, 0, 0>(0, a, n);
+    }
+}
+
+void Engine::poisson(int s0, int nb, bool store_phi) {
+    const int pairs = (nb + 1) / 2;
+    PoisArgs p{};
+    p.X = X_; p.W = W_; p.PHI = PHI_; p.n3 = n3_; p.active = st_.active; p.s0 = s0; p.nb = nb;
+    p.tw = tw_; p.ksq = ksq_; p.mass_factor = c_.mass_factor; p.pois_c = c_.pois_c; p.fourpi2 = c_.fourpi2;
+    p.inv_n3 = c_.inv_n3; p.maxphi = st_.maxphi;
+    PsiArgs a{};
+    a.src = W_; a.dst = W_; a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = nb; a.tw = tw_; a.scale = (real)1;
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using G = Geom<N>;
+        const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)pairs);
+        const dim3 block(G::THREADS);
+        k_rho_pass<N><<<grid, block, 0, stream_>>>(p);
+        k_psi_pass<N, -1, 1, 0, 0><<<grid, block, 0, stream_>>>(a);
+        k_poisson_mid<N><<<grid, block, 0, stream_>>>(p);
+        k_psi_pass<N, +1, 1, 0, 0><<<grid, block, 0, stream_>>>(a);
+        if (store_phi) k_phi_out<N, 1><<<grid, block, 0, stream_>>>(p);
+        else k_phi_out<N, 0><<<grid, block, 0, stream_>>>(p);
+    });
+    if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
+}
+
+// psi_k = F[psi] before the first step (simulation_object.rs:477-479)
+void Engine::ensure_kspace(int s0, int nb) { fft3_plain(X_, K_, s0, nb, -1, st_.active); }
+
+// potential at t and the timestep (simulation_object.rs:497-500)
+void Engine::step_front(int s0, int nb) {
+    k_zero_reductions<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, s0, nb);
+    poisson(s0, nb, false);
+    k_timestep<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb);
+}
+
+// drift/2, F^-1, potential, kick, F, drift/2, F^-1, bookkeeping (:504-635)
+void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau) {
+    k_drift_table<<<dim3((N_ + 63) / 64, nb), 64, 0, stream_>>>(st_, c_, ksq_, s0);
+    PsiArgs a{};
+    a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.drift = st_.drift;
+    a.phi = PHI_; a.kick = st_.kick; a.alias_sum = st_.alias_sum; a.ksq = ksq_; a.alias_cut = c_.alias_cut;
+    a.fourpi2 = c_.fourpi2; a.scale = (real)1;
+    // psi = F^-1[ D psi_k ]
+    a.src = K_; a.dst = X_; launch_psi<+1, 1, 0>(2, a, nb);
+    a.src = X_;             launch_psi<+1, 1, 0>(1, a, nb);
+    a.scale = c_.unit_scale; launch_psi<+1, 1, 0>(0, a, nb);
+    // phi at the half-drifted psi
+    poisson(s0, nb, true);
+    // psi_k = D F[ kick psi ]
+    a.scale = (real)1;
+    a.src = X_; a.dst = X_;  launch_psi<-1, 2, 1>(0, a, nb);
+                             launch_psi<-1, 0, 1>(1, a, nb);
+    a.dst = K_; a.scale = c_.unit_scale; launch_psi<-1, 0, 2>(2, a, nb);
+    // psi = F^-1[ psi_k ]
+    a.scale = (real)1;
+    a.src = K_; a.dst = X_;  launch_psi<+1, 0, 0>(2, a, nb);
+    a.src = X_;              launch_psi<+1, 0, 0>(1, a, nb);
+    a.scale = c_.unit_scale; launch_psi<+1, 0, 0>(0, a, nb);
+    k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+}
+
+int Engine::step(std::string& err) {
+    if (cfg_.expanding) { err = "expanding contexts step with msm_step_begin / msm_step_end"; return MSM_ERR_STATE; }
+    if (in_step_) { err = "msm_step inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    for (int s0 = 0; s0 < ns_; s0 += batch_) {
+        const int nb = std::min(batch_, ns_ - s0);
+        bool any = false;
+        for (int i = 0; i < nb; ++i) any = any || host_active_[s0 + i];
+        if (!any) continue;
+        if (!kspace_valid_) ensure_kspace(s0, nb);
+        step_front(s0, nb);
+        step_back(s0, nb, nullptr, nullptr, nullptr);
+    }
+    kspace_valid_ = true;
+    publish();
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::step_begin(const double* a_now, const double* tau_next, std::string& err) {
+    if (!cfg_.expanding) { err = "msm_step_begin is for expanding contexts"; return MSM_ERR_STATE; }
+    if (in_step_) { err = "msm_step_begin called twice"; return MSM_ERR_STATE; }
+    if (ns_ > batch_) { err = "expanding contexts need batch_streams >= n_streams"; return MSM_ERR_STATE; }
+    if (!a_now || !tau_next) { err = "null input"; return MSM_ERR_INVALID; }
+    std::vector<real> a(ns_), t(ns_);
+    for (int s = 0; s < ns_; ++s) { a[s] = (real)a_now[s]; t[s] = (real)tau_next[s]; }
+    HIP_TRY(hipMemcpyAsync(st_.a_now, a.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(st_.tau_next, t.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));  // the host vectors die here
+    if (!kspace_valid_) ensure_kspace(0, ns_);
+    kspace_valid_ = true;
+    step_front(0, ns_);
+    publish();
+    in_step_ = true;
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::step_end(const double* kick_a, const double* new_time, const double* new_tau,
+                     const double* snapped_tau, std::string& err) {
+    if (!in_step_) { err = "msm_step_end without msm_step_begin"; return MSM_ERR_STATE; }
+    if (!kick_a || !new_time || !new_tau || !snapped_tau) { err = "null input"; return MSM_ERR_INVALID; }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<real> k(ns_), nt(ns_), ntau(ns_), stau(ns_);
+    for (int s = 0; s < ns_; ++s) {
+        // two half-kicks exp(-i dtau/2 a1 phi) exp(-i dtau/2 a2 phi) on one phi (:726-742)
+        const real dtau = (real)h_status_[s].dt;
+        k[s] = -dtau / (real)2.0 * (real)kick_a[s];
+        nt[s] = (real)new_time[s]; ntau[s] = (real)new_tau[s]; stau[s] = (real)snapped_tau[s];
+    }
+    HIP_TRY(hipMemcpyAsync(st_.kick, k.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_in_[0], nt.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_in_[1], ntau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_in_[2], stau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    step_back(0, ns_, d_in_[0], d_in_[1], d_in_[2]);
+    publish();
+    in_step_ = false;
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::sync(std::string& err) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int s = 0; s < ns_; ++s) host_active_[s] = h_status_[s].active;
+    return MSM_OK;
+}
+
+int Engine::get_status(msm_stream_status* out, int n, std::string& err) {
+    if (!out || n < 0 || n > ns_) { err = "bad status buffer"; return MSM_ERR_INVALID; }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::memcpy(out, h_status_, sizeof(msm_stream_status) * n);
+    return MSM_OK;
+}
+
+int Engine::potential(int first, int count, std::string& err) {
+    if (first < 0 || count < 1 || first + count > ns_) { err = "stream range out of bounds"; return MSM_ERR_INVALID; }
+    if (count > 2 * ((batch_ + 1) / 2)) { err = "count exceeds the batch size"; return MSM_ERR_INVALID; }
+    k_zero_reductions<<<(count + 63) / 64, 64, 0, stream_>>>(st_, first, count);
+    poisson(first, count, true);
+    publish();
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::fft(int s, int dir, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (dir != MSM_FORWARD && dir != MSM_INVERSE) { err = "direction must be -1 or +1"; return MSM_ERR_INVALID; }
+    fft3_plain(X_, X_, s, 1, dir, nullptr);
+    kspace_valid_ = false;
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::set_psi(int s, const void* re, const void* im, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (!re || !im) { err = "null plane"; return MSM_ERR_INVALID; }
+    // stage the two planes in this stream's (not yet meaningful) psi_k slot halves
+    real* stage = (real*)(K_ + (size_t)s * n3_);
+    HIP_TRY(hipMemcpyAsync(stage, re, sizeof(real) * n3_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(stage + n3_, im, sizeof(real) * n3_, hipMemcpyHostToDevice, stream_));
+    k_interleave<<<2048, 256, 0, stream_>>>(X_ + (size_t)s * n3_, stage, stage + n3_, n3_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    kspace_valid_ = false;
+    return MSM_OK;
+}
+
+int Engine::copy_psi(int dst, int src, std::string& err) {
+    if (int rc = check_stream(dst, err)) return rc;
+    if (int rc = check_stream(src, err)) return rc;
+    if (dst == src) return MSM_OK;
+    HIP_TRY(hipMemcpyAsync(X_ + (size_t)dst * n3_, X_ + (size_t)src * n3_, sizeof(cplx) * n3_, hipMemcpyDeviceToDevice, stream_));
+    kspace_valid_ = false;
+    return MSM_OK;
+}
+
+int Engine::sample(int s, int scheme, uint64_t seed, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (scheme != MSM_WIGNER && scheme != MSM_HUSIMI) {
+        err = "only Wigner and Husimi sampling are reproducible (the reference's Poisson branch uses thread_rng)";
+        return MSM_ERR_INVALID;
+    }
+    const double n = cfg_.total_mass / cfg_.particle_mass;      // ics.rs:472
+    const real sqrt_n = (real)std::sqrt(n);
+    const real sqrt_dv = std::sqrt(std::pow(dx_, (real)dims_));  // ics.rs:479-489
+    const real div = scheme == MSM_WIGNER ? sqrt_n * (real)2.0 : sqrt_n * std::sqrt((real)2.0);
+    k_sample<<<2048, 256, 0, stream_>>>(X_ + (size_t)s * n3_, n3_, (unsigned long long)seed, sqrt_dv, div);
+    kspace_valid_ = false;
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (!re || !im) { err = "null plane"; return MSM_ERR_INVALID; }
+    if (kspace && !kspace_valid_) { err = "psi_k is only defined after the first step"; return MSM_ERR_STATE; }
+    const cplx* src = (kspace ? K_ : X_) + (size_t)s * n3_;
+    // split into W (free between steps) and copy the planes out
+    real* stage = (real*)W_;
+    k_split<<<2048, 256, 0, stream_>>>(src, stage, stage + n3_, n3_);
+    HIP_TRY(hipMemcpyAsync(re, stage, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(im, stage + n3_, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return MSM_OK;
+}
+
+int Engine::get_potential(int s, void* phi, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (!phi) { err = "null plane"; return MSM_ERR_INVALID; }
+    if (phi_s0_ < 0 || s < phi_s0_ || s >= phi_s0_ + phi_nb_) {
+        err = "potential of this stream is not resident (call msm_potential for its batch)";
+        return MSM_ERR_STATE;
+    }
+    HIP_TRY(hipMemcpyAsync(phi, PHI_ + (size_t)(s - phi_s0_) * n3_, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return MSM_OK;
+}
+
+int Engine::density_sum(void* dev_out, std::string& err) {
+    if (!dev_out) { err = "null output"; return MSM_ERR_INVALID; }
+    k_density_sum<<<2048, 256, 0, stream_>>>(X_, n3_, ns_, (double*)dev_out);
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::timer_start(std::string& err) {
+    HIP_TRY(hipEventRecord(ev0_, stream_));
+    return MSM_OK;
+}
+int Engine::timer_stop(float* ms, std::string& err) {
+    if (!ms) { err = "null output"; return MSM_ERR_INVALID; }
+    HIP_TRY(hipEventRecord(ev1_, stream_));
+    HIP_TRY(hipEventSynchronize(ev1_));
+    HIP_TRY(hipEventElapsedTime(ms, ev0_, ev1_));
+    return MSM_OK;
+}
+
+}  // namespace
+
+#define MSM_CAT2(a, b) a##b
+#define MSM_CAT(a, b) MSM_CAT2(a, b)
+IEngine* MSM_CAT(make_engine_, MSM_SUFFIX)(const msm_config& cfg) { return new Engine(cfg); }
+
+}  // namespace msm

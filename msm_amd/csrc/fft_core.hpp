@@ -1,0 +1,158 @@
+// Batched power-of-two complex FFT building blocks for gfx950 (wave64).
+//
+// One "line" of N points is owned by TPL = N/E threads; every thread keeps E
+// complex values in registers.  The transform is a Stockham autosort
+// factorisation N = R0*R1[*R2] (radices <= 16): each stage does E/R
+// register-resident radix-R butterflies per thread and, except after the last
+// stage, exchanges the line through LDS.  With this indexing a thread always
+// reads positions  j0 + TPL*q  (q = 0..E-1)  -- from global memory before the
+// first stage, from LDS before the later ones -- and after the last stage it
+// holds the natural-order outputs at those same positions, so the global
+// load and store patterns are identical and coalesce in runs of TPL elements
+// (contiguous axis) or LPW elements (strided axes, LPW neighbouring lines).
+//
+// Replaces the ArrayFire fft*/ifft* calls behind the reference's wrappers
+// (simulator/src/utils/fft.rs:6-98); sign convention forward = e^{-2 pi i kn/N}.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace msm {
+
+template <typename T> struct cx_of;
+template <> struct cx_of<double> { using type = double2; };
+template <> struct cx_of<float>  { using type = float2; };
+template <typename T> using cx = typename cx_of<T>::type;
+
+template <typename T> __device__ __forceinline__ cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
+template <typename C> __device__ __forceinline__ C cadd(C a, C b) { C r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+template <typename C> __device__ __forceinline__ C csub(C a, C b) { C r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+template <typename C> __device__ __forceinline__ C cmul(C a, C b) { C r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; }
+// a * conj(b)
+template <typename C> __device__ __forceinline__ C cmulc(C a, C b) { C r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r; }
+template <typename C, typename T> __device__ __forceinline__ C cscale(C a, T s) { C r; r.x = a.x * s; r.y = a.y * s; return r; }
+
+// cos/sin(2 pi m / 16), m = 0..7
+__device__ __forceinline__ constexpr double cos16(int m) {
+    constexpr double c1 = 0.92387953251128675613, c2 = 0.70710678118654752440, c3 = 0.38268343236508977173;
+    return m == 0 ? 1.0 : m == 1 ? c1 : m == 2 ? c2 : m == 3 ? c3 : m == 4 ? 0.0 : m == 5 ? -c3 : m == 6 ? -c2 : -c1;
+}
+__device__ __forceinline__ constexpr double sin16(int m) {
+    constexpr double c1 = 0.92387953251128675613, c2 = 0.70710678118654752440, c3 = 0.38268343236508977173;
+    return m == 0 ? 0.0 : m == 1 ? c3 : m == 2 ? c2 : m == 3 ? c1 : m == 4 ? 1.0 : m == 5 ? c1 : m == 6 ? c2 : c3;
+}
+
+// In-register DFT of R points (R in {1,2,4,8,16}), natural order in and out.
+// SGN = -1 forward, +1 inverse.  Radix-2 decimation in time, fully unrolled.
+template <int R, int SGN, typename T>
+__device__ __forceinline__ void dft(cx<T> (&a)[R]) {
+    if constexpr (R == 2) {
+        cx<T> t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    } else if constexpr (R >= 4) {
+        constexpr int H = R / 2;
+        cx<T> e[H], o[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) { e[i] = a[2 * i]; o[i] = a[2 * i + 1]; }
+        dft<H, SGN, T>(e);
+        dft<H, SGN, T>(o);
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            cx<T> t;
+            constexpr int STEP = 16 / R;
+            const int m = k * STEP;  // twiddle W_R^k = exp(SGN * 2 pi i m / 16)
+            if (k == 0) {
+                t = o[k];
+            } else if (m == 4) {     // * (SGN * i)
+                t = mk<T>(-SGN * o[k].y, SGN * o[k].x);
+            } else {
+                const T c = (T)cos16(m), s = (T)(SGN * sin16(m));
+                t = mk<T>(o[k].x * c - o[k].y * s, o[k].x * s + o[k].y * c);
+            }
+            a[k] = cadd(e[k], t);
+            a[k + H] = csub(e[k], t);
+        }
+    }
+}
+
+// Factorisation table.  E = values per thread, S = stages.
+template <int N> struct Plan;
+template <> struct Plan<2>    { static constexpr int E = 2,  S = 1, R0 = 2,  R1 = 1,  R2 = 1; };
+template <> struct Plan<4>    { static constexpr int E = 4,  S = 1, R0 = 4,  R1 = 1,  R2 = 1; };
+template <> struct Plan<8>    { static constexpr int E = 8,  S = 1, R0 = 8,  R1 = 1,  R2 = 1; };
+template <> struct Plan<16>   { static constexpr int E = 16, S = 1, R0 = 16, R1 = 1,  R2 = 1; };
+template <> struct Plan<32>   { static constexpr int E = 16, S = 2, R0 = 16, R1 = 2,  R2 = 1; };
+template <> struct Plan<64>   { static constexpr int E = 16, S = 2, R0 = 16, R1 = 4,  R2 = 1; };
+template <> struct Plan<128>  { static constexpr int E = 16, S = 2, R0 = 16, R1 = 8,  R2 = 1; };
+template <> struct Plan<256>  { static constexpr int E = 16, S = 2, R0 = 16, R1 = 16, R2 = 1; };
+template <> struct Plan<512>  { static constexpr int E = 16, S = 3, R0 = 16, R1 = 16, R2 = 2; };
+
+template <int N> struct Geom {
+    using P = Plan<N>;
+    static constexpr int E = P::E;
+    static constexpr int TPL = N / E;                  // threads per line
+    static constexpr int LPW = N < 16 ? N : 16;        // lines per workgroup
+    static constexpr int THREADS = TPL * LPW;
+    static constexpr int LINE_LDS = N + (N >> 4) + 1;  // padded line length in LDS (elements)
+    static constexpr bool USES_LDS = P::S > 1;
+    // LDS elements: LPW padded lines + the N-entry twiddle table.
+    static constexpr int LDS_ELEMS = USES_LDS ? (LPW * LINE_LDS + N) : 1;
+};
+
+__device__ __forceinline__ int lds_pad(int p) { return p + (p >> 4); }
+
+// Runs all stages of one length-N transform on the E register values of this
+// thread.  `line` points at this line's padded LDS region, `tw` at the
+// LDS-resident table tw[p] = exp(-2 pi i p / N).  Contains __syncthreads():
+// every thread of the workgroup must call it.
+template <typename T, int N, int SGN>
+struct LineFft {
+    using P = Plan<N>;
+    using G = Geom<N>;
+    static constexpr int E = P::E, TPL = G::TPL;
+
+    template <int SIDX, int NS>
+    static __device__ __forceinline__ void stage(cx<T> (&v)[E], int j0, cx<T>* line, const cx<T>* tw) {
+        constexpr int R = SIDX == 0 ? P::R0 : (SIDX == 1 ? P::R1 : P::R2);
+        constexpr int BPT = E / R;
+        constexpr bool LAST = (SIDX == P::S - 1);
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const int b = j0 + TPL * u;
+            const int k = b & (NS - 1);
+            cx<T> a[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) a[t] = v[u + t * BPT];
+            if constexpr (NS > 1) {
+                constexpr int TWS = N / (NS * R);
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    const cx<T> w = tw[k * t * TWS];
+                    a[t] = (SGN < 0) ? cmul(a[t], w) : cmulc(a[t], w);
+                }
+            }
+            dft<R, SGN, T>(a);
+            if constexpr (LAST) {
+#pragma unroll
+                for (int t = 0; t < R; ++t) v[u + t * BPT] = a[t];
+            } else {
+                const int o = (b - k) * R + k;
+#pragma unroll
+                for (int t = 0; t < R; ++t) line[lds_pad(o + t * NS)] = a[t];
+            }
+        }
+        if constexpr (!LAST) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = line[lds_pad(j0 + TPL * q)];
+            if constexpr (SIDX + 2 < P::S) __syncthreads();
+            stage<SIDX + 1, NS * R>(v, j0, line, tw);
+        }
+    }
+
+    static __device__ __forceinline__ void run(cx<T> (&v)[E], int j0, cx<T>* line, const cx<T>* tw) {
+        stage<0, 1>(v, j0, line, tw);
+    }
+};
+
+}  // namespace msm

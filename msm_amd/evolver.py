@@ -1,0 +1,185 @@
+"""Host-side handle on one GPU's batch of streams (thin layer over the C ABI).
+
+Names follow the reference's `SimulationObject` (simulator/src/simulation_object.rs):
+`update` is one split-step update of every active stream, `calculate_potential`,
+`get_timestep`-derived quantities come back in `status()`, `forward`/`inverse` are
+the unitary FFT wrappers of simulator/src/utils/fft.rs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+HBAR = 1.757e-90  # common/src/constants.rs:5
+
+
+class MsmError(RuntimeError):
+    pass
+
+
+def determine_pmass_hbar_(total_mass, ntot=None, particle_mass=None, hbar_=None):
+    """common/src/parameters.rs:222-259: resolution order ntot -> particle_mass -> hbar_."""
+    if ntot is not None:
+        pm = total_mass / ntot
+        hb = hbar_ if hbar_ is not None else HBAR / pm
+    elif particle_mass is not None:
+        pm = particle_mass
+        hb = hbar_ if hbar_ is not None else HBAR / pm
+    elif hbar_ is not None:
+        hb = hbar_
+        pm = HBAR / hb
+    else:
+        raise ValueError("You must specify the total mass and one of ntot, particle_mass or hbar_")
+    return pm, hb
+
+
+class Evolver:
+    def __init__(self, *, size: int, n_streams: int, axis_length: float, final_sim_time: float, cfl: float,
+                 num_data_dumps: int, total_mass: float, k2_cutoff: float, alias_threshold: float,
+                 hbar_: Optional[float] = None, particle_mass: Optional[float] = None,
+                 ntot: Optional[float] = None, time: float = 0.0, dims: int = 3, precision: str = "f64",
+                 batch_streams: int = 0, cosmology: Optional[dict] = None, device: int = 0,
+                 hip_stream: Optional[int] = None):
+        self._lib = L.load()
+        pm, hb = determine_pmass_hbar_(total_mass, ntot, particle_mass, hbar_)
+        cfg = L.MsmConfig()
+        cfg.struct_size = C.sizeof(L.MsmConfig)
+        cfg.device, cfg.dims, cfg.size = device, dims, size
+        cfg.precision = {"f64": L.MSM_F64, "f32": L.MSM_F32}[precision]
+        cfg.n_streams, cfg.batch_streams = n_streams, batch_streams
+        cfg.expanding = 1 if cosmology else 0
+        cfg.axis_length, cfg.time, cfg.final_sim_time, cfg.cfl = axis_length, time, final_sim_time, cfl
+        cfg.num_data_dumps = num_data_dumps
+        cfg.total_mass, cfg.particle_mass, cfg.hbar_ = total_mass, pm, hb
+        cfg.k2_cutoff, cfg.alias_threshold = k2_cutoff, alias_threshold
+        if cosmology:
+            cfg.omega_matter_now = cosmology["omega_matter_now"]
+            cfg.omega_radiation_now = cosmology["omega_radiation_now"]
+            cfg.h, cfg.z0 = cosmology["h"], cosmology["z0"]
+            cfg.max_dloga = cosmology.get("max_dloga") or 0.0
+        cfg.hip_stream = hip_stream
+        self.cfg = cfg
+        self.size, self.dims, self.n_streams = size, dims, n_streams
+        self.real = np.float64 if precision == "f64" else np.float32
+        self.cplx = np.complex128 if precision == "f64" else np.complex64
+        self.shape = (size,) * dims
+        self._ctx = C.c_void_p()
+        rc = self._lib.msm_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != 0:
+            raise MsmError(f"msm_create failed ({rc}): {self._lib.msm_last_error(None).decode()}")
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise MsmError(f"{what} failed ({rc}): {self._lib.msm_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.msm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def batch_streams(self) -> int:
+        b = C.c_int32()
+        self._check(self._lib.msm_get_batch(self._ctx, C.byref(b)), "msm_get_batch")
+        return b.value
+
+    def derived(self) -> dict:
+        out = (C.c_double * 8)()
+        self._check(self._lib.msm_get_derived(self._ctx, out), "msm_get_derived")
+        keys = ["dx", "dk", "k2_max", "hbar_", "n_tot", "kinetic_dt", "comoving_boxsize"]
+        return dict(zip(keys, list(out)[:7]))
+
+    # -- initial conditions ----------------------------------------------
+    def set_psi(self, stream: int, psi: np.ndarray):
+        if psi.shape != self.shape:
+            raise ValueError(f"psi has shape {psi.shape}, expected {self.shape}")
+        re = np.ascontiguousarray(psi.real, dtype=self.real)
+        im = np.ascontiguousarray(psi.imag, dtype=self.real)
+        self._check(self._lib.msm_set_psi(self._ctx, stream, re.ctypes.data, im.ctypes.data), "msm_set_psi")
+
+    def copy_psi(self, dst: int, src: int):
+        self._check(self._lib.msm_copy_psi(self._ctx, dst, src), "msm_copy_psi")
+
+    def sample(self, stream: int, scheme: str, seed: int):
+        code = {"Poisson": L.MSM_POISSON, "Wigner": L.MSM_WIGNER, "Husimi": L.MSM_HUSIMI}[scheme]
+        self._check(self._lib.msm_sample(self._ctx, stream, code, seed), "msm_sample")
+
+    # -- operators --------------------------------------------------------
+    def forward(self, stream: int):
+        self._check(self._lib.msm_fft(self._ctx, stream, L.MSM_FORWARD), "msm_fft")
+
+    def inverse(self, stream: int):
+        self._check(self._lib.msm_fft(self._ctx, stream, L.MSM_INVERSE), "msm_fft")
+
+    def calculate_potential(self, first: int = 0, count: Optional[int] = None):
+        count = self.n_streams - first if count is None else count
+        self._check(self._lib.msm_potential(self._ctx, first, count), "msm_potential")
+
+    def update(self):
+        self._check(self._lib.msm_step(self._ctx), "msm_step")
+
+    def step_begin(self, a_now, tau_to_next_dump):
+        a = np.ascontiguousarray(a_now, dtype=np.float64)
+        t = np.ascontiguousarray(tau_to_next_dump, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.msm_step_begin(self._ctx, a.ctypes.data_as(dp), t.ctypes.data_as(dp)),
+                    "msm_step_begin")
+
+    def step_end(self, kick_a, new_time, new_tau, snapped_tau):
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (kick_a, new_time, new_tau, snapped_tau)]
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.msm_step_end(self._ctx, *[x.ctypes.data_as(dp) for x in arrs]), "msm_step_end")
+
+    def sync(self):
+        self._check(self._lib.msm_sync(self._ctx), "msm_sync")
+
+    def status(self):
+        buf = (L.MsmStreamStatus * self.n_streams)()
+        self._check(self._lib.msm_get_status(self._ctx, buf, self.n_streams), "msm_get_status")
+        return list(buf)
+
+    # -- downloads ----------------------------------------------------------
+    def _get_c(self, fn, name, stream):
+        re = np.empty(self.shape, dtype=self.real)
+        im = np.empty(self.shape, dtype=self.real)
+        self._check(fn(self._ctx, stream, re.ctypes.data, im.ctypes.data), name)
+        return (re + 1j * im).astype(self.cplx)
+
+    def get_psi(self, stream: int) -> np.ndarray:
+        return self._get_c(self._lib.msm_get_psi, "msm_get_psi", stream)
+
+    def get_psik(self, stream: int) -> np.ndarray:
+        return self._get_c(self._lib.msm_get_psik, "msm_get_psik", stream)
+
+    def get_potential(self, stream: int) -> np.ndarray:
+        phi = np.empty(self.shape, dtype=self.real)
+        self._check(self._lib.msm_get_potential(self._ctx, stream, phi.ctypes.data), "msm_get_potential")
+        return phi
+
+    def density_sum(self, device_ptr: int):
+        self._check(self._lib.msm_density_sum(self._ctx, device_ptr), "msm_density_sum")
+
+    def timer_start(self):
+        self._check(self._lib.msm_timer_start(self._ctx), "msm_timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.msm_timer_stop_ms(self._ctx, C.byref(ms)), "msm_timer_stop_ms")
+        return ms.value

@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/msm.h declares.
+No compute call is made here (there is no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import msm_amd
+from msm_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "msm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    names = _declared()
+    assert len(names) >= 20
+    lib = msm_amd.load()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/msm.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "msm_amd/_lib.py binds a different set than the header declares"
+
+
+def test_struct_layout_matches_header():
+    # sizes the C compiler gives for the two structs of include/msm.h
+    assert ctypes.sizeof(_lib.MsmConfig) == 160
+    assert ctypes.sizeof(_lib.MsmStreamStatus) == 64
+
+
+def test_create_rejects_bad_config_without_gpu():
+    lib = msm_amd.load()
+    ctx = ctypes.c_void_p()
+    cfg = _lib.MsmConfig()
+    cfg.struct_size = 1
+    assert lib.msm_create(ctypes.byref(cfg), ctypes.byref(ctx)) == -1
+    assert b"struct_size" in lib.msm_last_error(None)
+    assert lib.msm_create(None, ctypes.byref(ctx)) == -1
+    assert lib.msm_step(None) == -1
+
+
+def test_pmass_hbar_resolution():
+    # common/src/parameters.rs:222-259
+    pm, hb = msm_amd.determine_pmass_hbar_(3e16, ntot=1e10, hbar_=0.01)
+    assert pm == 3e16 / 1e10 and hb == 0.01
+    pm, hb = msm_amd.determine_pmass_hbar_(1e11, hbar_=0.05)
+    assert hb == 0.05 and pm == 1.757e-90 / 0.05
+    pm, hb = msm_amd.determine_pmass_hbar_(1.0, particle_mass=2.0)
+    assert pm == 2.0 and hb == 1.757e-90 / 2.0
