@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stream-cell updates/s of the split-step update at 256^3 x 256 streams fp64.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one SimulationObject::update of every stream.  The 256 streams are
+block-partitioned over the N ranks (one process per GPU, no data-path exchange
+between streams); with N > 1 every step also sums |psi|^2 over the local
+streams and all-reduces that mean-density grid over RCCL.  Inputs are synthetic:
+the reference's plane-wave ICs (sim.py) regenerated at N = 256 plus Wigner
+noise per stream seed, resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant pass kernel,
+timed with HIP events inside the timed region; `cpu_baseline` is the numpy
+oracle (a port of the reference algorithm) timed on this host on one stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import msm_amd  # noqa: E402
+from msm_amd.ics import plane_wave_psi  # noqa: E402
+
+PLANE = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=64, total_mass=3e16,
+             hbar_=0.01, ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+B_ALG_STEP = 224.0             # algorithmic bytes per stream-cell update, fp64: 7 transforms x (16 B in + 16 B out)
+B_ALG_PASS = 32.0 / 3.0        # one axis pass is a third of a transform under the same model
+B_MOVED_PASS = 32.0            # what a pass kernel actually reads + writes per cell (complex128 in, complex128 out)
+
+
+def cpu_baseline(size, seconds_cap=40.0):
+    """Oracle (numpy port of the reference step) on one stream of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sp_oracle as o  # checker / baseline leg only
+
+    toml = dict(PLANE, sim_name="cpu", dims=3, size=size, ics=dict(type="none"))
+    params = list(o.simulation_iter(toml))[-1]
+    psi = o.sample_quantum_perturbation(o.plane_wave_ics(size), params.dx, 3, params.total_mass,
+                                        params.particle_mass, "Wigner", 1)
+    sim = o.SimulationObject(params, psi=psi)
+    sim.update()  # includes the one-off psi_k = F psi
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 2 and time.perf_counter() - t0 < seconds_cap / 2:
+        sim.update()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=size ** 3 * steps / dt, unit="stream-cell updates/s", cores=1, kind="port",
+                sample=f"{size}^3 fp64, 1 stream, {steps} timed steps (numpy oracle, single thread)",
+                seconds=round(dt, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=256, help="total streams over all GPUs")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    N = args.size
+    n3 = N ** 3
+
+    dist = torch = None
+    hip_stream = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        hip_stream = torch.cuda.current_stream().cuda_stream or None
+
+    # block partition of the seed list 1..streams (simulator/src/utils/io.rs:183-213 order)
+    per = (args.streams + world - 1) // world
+    first = rank * per
+    n_local = max(0, min(per, args.streams - first))
+    seeds = [first + 1 + i for i in range(n_local)]
+
+    ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank,
+                         hip_stream=hip_stream, **PLANE)
+    psi0 = plane_wave_psi(N)
+    ev.set_psi(0, psi0)
+    for s in range(1, n_local):
+        ev.copy_psi(s, 0)
+    for s, seed in enumerate(seeds):
+        ev.sample(s, "Wigner", seed)       # stochastic stream resampling, one seed per stream
+    del psi0
+
+    dens = work = None
+    if world > 1:
+        dens = [torch.empty(n3, dtype=torch.float64, device="cuda") for _ in range(2)]
+        work = [None, None]
+
+    def one_step(i):
+        ev.update()
+        if world > 1:
+            b = i & 1
+            if work[b] is not None:
+                work[b].wait()
+            ev.density_sum(dens[b].data_ptr())
+            work[b] = dist.all_reduce(dens[b], async_op=True)   # sum over ranks; mean = / streams
+        ev.sync()                                               # per-step status (dt, dump flags) on the host
+
+    def barrier():
+        ev.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    ev.profile(True)
+    ev.timer_start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    if world > 1:
+        for w in work:
+            if w is not None:
+                w.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev.timer_stop_ms()
+    prof = ev.profile_report()
+    ev.profile(False)
+    st = ev.status()
+    steps_done = min(s.n_steps for s in st) - args.warmup if n_local else args.steps
+    aliased = sum(s.aliased for s in st)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        if steps_done != args.steps or aliased:
+            raise SystemExit(f"invalid run: {steps_done} of {args.steps} steps done, {aliased} streams aliased")
+        value = n3 * args.streams * args.steps / elapsed
+        # dominant kernel = the pass kind with the largest total time
+        kind, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        pair = kind in ("w_fwd_y", "poisson_z", "w_inv_y")         # these work on one complex grid per stream PAIR
+        cells_per_launch = n3 * min(args.batch, n_local) * (0.5 if pair else 1.0)
+        avg_s = kms / kcnt / 1e3
+        achieved = B_ALG_PASS * cells_per_launch / avg_s / 1e9
+        roofline = dict(bound="hbm", kernel=kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        avg_launch_ms=round(kms / kcnt, 4), launches=int(kcnt),
+                        alg_bytes_per_launch=B_ALG_PASS * cells_per_launch,
+                        moved_gbs=round(B_MOVED_PASS * cells_per_launch / avg_s / 1e9, 1),
+                        step_alg_gbs=round(value * B_ALG_STEP / world / 1e9, 1),
+                        step_frac=round(value * B_ALG_STEP / world / 1e9 / HBM_PEAK_GBS, 4),
+                        per_kind_ms={k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()})
+        out = {
+            "metric": "stream-cell updates/sec (N^3*N_streams/step) at 256^3x256; % HBM roofline",
+            "value": value, "unit": "stream-cell updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{N}^3 fp64 x {args.streams} streams, plane-wave ICs + Wigner noise "
+                                   f"(tomls/planeWave3d_e10_sym.toml, size override), static box",
+                       "streams_per_gpu": per, "batch_streams": args.batch,
+                       "density_allreduce": world > 1, "event_ms_per_step": ev_ms / args.steps},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N)
+        print(json.dumps(out), flush=True)
+
+    ev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,15 @@ int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64);
 int32_t msm_timer_start(msm_ctx* ctx);
 int32_t msm_timer_stop_ms(msm_ctx* ctx, float* ms);
 
+/* Per-launch timing of the pass kernels with HIP events on the launch stream
+ * (no counterpart in the reference; measurement hook for benchmarks).
+ * msm_profile(ctx, 1) starts recording, msm_profile_report sums elapsed ms and
+ * launch counts per pass kind (msm_profile_kind_name) and clears the records.
+ * max_kinds must be >= 16. */
+int32_t msm_profile(msm_ctx* ctx, int32_t enable);
+int32_t msm_profile_report(msm_ctx* ctx, int32_t max_kinds, double* total_ms, int64_t* launches, int32_t* n_kinds);
+const char* msm_profile_kind_name(int32_t kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ SYMBOLS = {
     "msm_density_sum": (C.c_int32, [_P, _P]),
     "msm_timer_start": (C.c_int32, [_P]),
     "msm_timer_stop_ms": (C.c_int32, [_P, C.POINTER(C.c_float)]),
+    "msm_profile": (C.c_int32, [_P, C.c_int32]),
+    "msm_profile_report": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int32)]),
+    "msm_profile_kind_name": (C.c_char_p, [C.c_int32]),
 }
 
 _lib = None

@@ -140,4 +140,18 @@ int32_t msm_timer_stop_ms(msm_ctx* ctx, float* ms) {
     return ctx->eng->timer_stop(ms, ctx->err);
 }
 
+int32_t msm_profile(msm_ctx* ctx, int32_t enable) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->profile(enable, ctx->err);
+}
+int32_t msm_profile_report(msm_ctx* ctx, int32_t max_kinds, double* total_ms, int64_t* launches, int32_t* n_kinds) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->profile_report(max_kinds, total_ms, (long long*)launches, n_kinds, ctx->err);
+}
+const char* msm_profile_kind_name(int32_t kind) {
+    static const char* names[] = {"psi_inv_x", "psi_inv_y", "psi_inv_z", "psi_fwd_x", "psi_fwd_y", "psi_fwd_z",
+                                  "rho_fwd_x", "w_fwd_y", "poisson_z", "w_inv_y", "phi_inv_x"};
+    return (kind >= 0 && kind < 11) ? names[kind] : "";
+}
+
 }  // extern "C"

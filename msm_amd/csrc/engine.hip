@@ -351,12 +351,12 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_poisson_mid(PoisArgs a) {
 
 // x-pass, inverse: split phi_a / phi_b, track max|phi| per stream
 // (real(phi) simulation_object.rs:1109; max_all(abs(phi)) :905).
-template <int N, int STOREPHI>
+template <int N, int STOREPHI, int TRACKMAX>
 __global__ __launch_bounds__(Geom<N>::THREADS) void k_phi_out(PoisArgs a) {
     using G = Geom<N>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
-    __shared__ double red[G::THREADS];
+    __shared__ double red[TRACKMAX ? G::THREADS : 1];
     const int p = blockIdx.y;
     const int sa = a.s0 + 2 * p, sb = sa + 1;
     const bool has_b = (2 * p + 1 < a.nb);
@@ -383,17 +383,21 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_phi_out(PoisArgs a) {
             pa[g] = v[q].x;
             if (has_b) pb[g] = v[q].y;
         }
-        const double ax = fabs((double)v[q].x), ay = fabs((double)v[q].y);
-        ma = (ax != ax) ? ax : ((ma != ma) ? ma : (ax > ma ? ax : ma));
-        mb = (ay != ay) ? ay : ((mb != mb) ? mb : (ay > mb ? ay : mb));
+        if constexpr (TRACKMAX) {
+            const double ax = fabs((double)v[q].x), ay = fabs((double)v[q].y);
+            ma = (ax != ax) ? ax : ((ma != ma) ? ma : (ax > ma ? ax : ma));
+            mb = (ay != ay) ? ay : ((mb != mb) ? mb : (ay > mb ? ay : mb));
+        }
     }
-    const double ra = block_max<G::THREADS>(ma, red);
-    __syncthreads();
-    const double rb = block_max<G::THREADS>(mb, red);
-    if (threadIdx.x == 0) {
-        // non-negative doubles (and NaN, which sorts above them) order like their bit patterns
-        atomicMax(&a.maxphi[sa], (unsigned long long)__double_as_longlong(ra));
-        if (has_b) atomicMax(&a.maxphi[sb], (unsigned long long)__double_as_longlong(rb));
+    if constexpr (TRACKMAX) {
+        const double ra = block_max<G::THREADS>(ma, red);
+        __syncthreads();
+        const double rb = block_max<G::THREADS>(mb, red);
+        if (threadIdx.x == 0) {
+            // non-negative doubles (and NaN, which sorts above them) order like their bit patterns
+            atomicMax(&a.maxphi[sa], (unsigned long long)__double_as_longlong(ra));
+            if (has_b) atomicMax(&a.maxphi[sb], (unsigned long long)__double_as_longlong(rb));
+        }
     }
 }
 
@@ -584,6 +588,12 @@ bool dispatch_n(int N, F&& f) {
 // ---------------------------------------------------------------------------
 // the engine
 // ---------------------------------------------------------------------------
+enum ProfKind {
+    PK_PSI_INV_X = 0, PK_PSI_INV_Y, PK_PSI_INV_Z,      // psi <- F^-1 psi_k passes (drift on load when stepping)
+    PK_PSI_FWD_X, PK_PSI_FWD_Y, PK_PSI_FWD_Z,          // psi_k <- F psi passes (x: kick on load; z: alias sum)
+    PK_RHO_X, PK_W_FWD_Y, PK_POISSON_Z, PK_W_INV_Y, PK_PHI_X,   // Poisson solve on stream pairs
+    PK_COUNT
+};
 class Engine final : public IEngine {
   public:
     explicit Engine(const msm_config& cfg) : cfg_(cfg) {}
@@ -621,10 +631,10 @@ class Engine final : public IEngine {
     }
     // one axis pass of a psi-type transform
     template <int SGN, int LOAD, int STORE>
-    void launch_psi(int ax, const PsiArgs& a, int nblk_y);
+    void launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind = -1);
     // whole 3-D transforms
     void fft3_plain(cplx* src, cplx* dst, int s0, int n, int sgn, const int* active);
-    void poisson(int s0, int nb, bool store_phi);
+    void poisson(int s0, int nb, bool store_phi, bool track_max);
     void step_front(int s0, int nb);
     void step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
     void ensure_kspace(int s0, int nb);
@@ -648,6 +658,30 @@ class Engine final : public IEngine {
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
+
+    // optional per-launch timing (HIP events on the launch stream), bucketed by pass kind
+    struct ProfRec { int kind; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_;
+    std::vector<hipEvent_t> ev_pool_;
+    bool prof_on_ = false;
+    hipEvent_t pool_event() {
+        if (!ev_pool_.empty()) { hipEvent_t e = ev_pool_.back(); ev_pool_.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    template <typename F> void timed(int kind, F&& launch) {
+        if (!prof_on_) { launch(); return; }
+        ProfRec r{kind, pool_event(), pool_event()};
+        (void)hipEventRecord(r.a, stream_);
+        launch();
+        (void)hipEventRecord(r.b, stream_);
+        prof_.push_back(r);
+    }
+
+  public:
+    int profile(int enable, std::string& err) override;
+    int profile_report(int max_kinds, double* total_ms, long long* launches, int* n_kinds, std::string& err) override;
 };
 
 void Engine::release() {
@@ -655,6 +689,10 @@ void Engine::release() {
     allocs_.clear();
     if (h_status_) (void)hipHostFree(h_status_);
     h_status_ = nullptr;
+    for (auto& r : prof_) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    prof_.clear();
+    for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
+    ev_pool_.clear();
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -683,8 +721,8 @@ int Engine::init(std::string& err) {
 
     // sub-batch: bounded scratch (W + PHI = 2 real grids per stream), even count
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
+    if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;   // whole Poisson pairs in every full batch
     if (batch_ > ns_) batch_ = ns_;
-    if (batch_ > 1 && (batch_ & 1)) batch_ -= 1;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
     const real L = (real)cfg_.axis_length;
@@ -810,15 +848,18 @@ void Engine::publish() {
 }
 
 template <int SGN, int LOAD, int STORE>
-void Engine::launch_psi(int ax, const PsiArgs& a, int nblk_y) {
-    dispatch_n(N_, [&](auto nc) {
-        constexpr int N = decltype(nc)::value;
-        using G = Geom<N>;
-        const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)nblk_y);
-        const dim3 block(G::THREADS);
-        if (ax == 0) k_psi_pass<N, SGN, 0, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
-        else if (ax == 1) k_psi_pass<N, SGN, 1, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
-        else k_psi_pass<N, SGN, 2, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+void Engine::launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind) {
+    if (kind < 0) kind = SGN > 0 ? (PK_PSI_INV_X + ax) : (PK_PSI_FWD_X + ax);
+    timed(kind, [&] {
+        dispatch_n(N_, [&](auto nc) {
+            constexpr int N = decltype(nc)::value;
+            using G = Geom<N>;
+            const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)nblk_y);
+            const dim3 block(G::THREADS);
+            if (ax == 0) k_psi_pass<N, SGN, 0, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+            else if (ax == 1) k_psi_pass<N, SGN, 1, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+            else k_psi_pass<N, SGN, 2, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+        });
     });
 }
 
@@ -837,7 +878,7 @@ void Engine::fft3_plain(cplx* src, cplx* dst, int s0, int n, int sgn, const int*
     }
 }
 
-void Engine::poisson(int s0, int nb, bool store_phi) {
+void Engine::poisson(int s0, int nb, bool store_phi, bool track_max) {
     const int pairs = (nb + 1) / 2;
     PoisArgs p{};
     p.X = X_; p.W = W_; p.PHI = PHI_; p.n3 = n3_; p.active = st_.active; p.s0 = s0; p.nb = nb;
@@ -850,12 +891,15 @@ void Engine::poisson(int s0, int nb, bool store_phi) {
         using G = Geom<N>;
         const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)pairs);
         const dim3 block(G::THREADS);
-        k_rho_pass<N><<<grid, block, 0, stream_>>>(p);
-        k_psi_pass<N, -1, 1, 0, 0><<<grid, block, 0, stream_>>>(a);
-        k_poisson_mid<N><<<grid, block, 0, stream_>>>(p);
-        k_psi_pass<N, +1, 1, 0, 0><<<grid, block, 0, stream_>>>(a);
-        if (store_phi) k_phi_out<N, 1><<<grid, block, 0, stream_>>>(p);
-        else k_phi_out<N, 0><<<grid, block, 0, stream_>>>(p);
+        timed(PK_RHO_X, [&] { k_rho_pass<N><<<grid, block, 0, stream_>>>(p); });
+        timed(PK_W_FWD_Y, [&] { k_psi_pass<N, -1, 1, 0, 0><<<grid, block, 0, stream_>>>(a); });
+        timed(PK_POISSON_Z, [&] { k_poisson_mid<N><<<grid, block, 0, stream_>>>(p); });
+        timed(PK_W_INV_Y, [&] { k_psi_pass<N, +1, 1, 0, 0><<<grid, block, 0, stream_>>>(a); });
+        timed(PK_PHI_X, [&] {
+            if (store_phi && track_max) k_phi_out<N, 1, 1><<<grid, block, 0, stream_>>>(p);
+            else if (store_phi) k_phi_out<N, 1, 0><<<grid, block, 0, stream_>>>(p);
+            else k_phi_out<N, 0, 1><<<grid, block, 0, stream_>>>(p);
+        });
     });
     if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
@@ -866,7 +910,7 @@ void Engine::ensure_kspace(int s0, int nb) { fft3_plain(X_, K_, s0, nb, -1, st_.
 // potential at t and the timestep (simulation_object.rs:497-500)
 void Engine::step_front(int s0, int nb) {
     k_zero_reductions<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, s0, nb);
-    poisson(s0, nb, false);
+    poisson(s0, nb, false, true);
     k_timestep<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb);
 }
 
@@ -882,7 +926,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     a.src = X_;             launch_psi<+1, 1, 0>(1, a, nb);
     a.scale = c_.unit_scale; launch_psi<+1, 1, 0>(0, a, nb);
     // phi at the half-drifted psi
-    poisson(s0, nb, true);
+    poisson(s0, nb, true, false);   // max|phi| keeps the value that sized dt
     // psi_k = D F[ kick psi ]
     a.scale = (real)1;
     a.src = X_; a.dst = X_;  launch_psi<-1, 2, 1>(0, a, nb);
@@ -974,7 +1018,7 @@ int Engine::potential(int first, int count, std::string& err) {
     if (first < 0 || count < 1 || first + count > ns_) { err = "stream range out of bounds"; return MSM_ERR_INVALID; }
     if (count > 2 * ((batch_ + 1) / 2)) { err = "count exceeds the batch size"; return MSM_ERR_INVALID; }
     k_zero_reductions<<<(count + 63) / 64, 64, 0, stream_>>>(st_, first, count);
-    poisson(first, count, true);
+    poisson(first, count, true, true);
     publish();
     HIP_TRY(hipGetLastError());
     return MSM_OK;
@@ -1057,6 +1101,31 @@ int Engine::density_sum(void* dev_out, std::string& err) {
     if (!dev_out) { err = "null output"; return MSM_ERR_INVALID; }
     k_density_sum<<<2048, 256, 0, stream_>>>(X_, n3_, ns_, (double*)dev_out);
     HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::profile(int enable, std::string& err) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (auto& r : prof_) { ev_pool_.push_back(r.a); ev_pool_.push_back(r.b); }
+    prof_.clear();
+    prof_on_ = enable != 0;
+    return MSM_OK;
+}
+
+int Engine::profile_report(int max_kinds, double* total_ms, long long* launches, int* n_kinds, std::string& err) {
+    if (!total_ms || !launches || !n_kinds || max_kinds < PK_COUNT) { err = "report buffers too small"; return MSM_ERR_INVALID; }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int k = 0; k < PK_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; }
+    for (auto& r : prof_) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        total_ms[r.kind] += ms;
+        launches[r.kind] += 1;
+        ev_pool_.push_back(r.a);
+        ev_pool_.push_back(r.b);
+    }
+    prof_.clear();
+    *n_kinds = PK_COUNT;
     return MSM_OK;
 }
 

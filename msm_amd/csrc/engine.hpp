@@ -26,6 +26,9 @@ struct IEngine {
     virtual int density_sum(void* dev_out, std::string& err) = 0;
     virtual int timer_start(std::string& err) = 0;
     virtual int timer_stop(float* ms, std::string& err) = 0;
+    virtual int profile(int enable, std::string& err) = 0;
+    virtual int profile_report(int max_kinds, double* total_ms, long long* launches, int* n_kinds,
+                               std::string& err) = 0;
     virtual void derived(double out[8]) const = 0;
     virtual int batch() const = 0;
 };

@@ -183,3 +183,14 @@ class Evolver:
         ms = C.c_float()
         self._check(self._lib.msm_timer_stop_ms(self._ctx, C.byref(ms)), "msm_timer_stop_ms")
         return ms.value
+
+    def profile(self, enable: bool):
+        self._check(self._lib.msm_profile(self._ctx, 1 if enable else 0), "msm_profile")
+
+    def profile_report(self) -> dict:
+        """{pass kind: (total ms, launches)} since the last report."""
+        ms = (C.c_double * 16)()
+        cnt = (C.c_int64 * 16)()
+        n = C.c_int32()
+        self._check(self._lib.msm_profile_report(self._ctx, 16, ms, cnt, C.byref(n)), "msm_profile_report")
+        return {self._lib.msm_profile_kind_name(k).decode(): (ms[k], cnt[k]) for k in range(n.value)}
