@@ -12,8 +12,8 @@ the reference's plane-wave ICs (sim.py) regenerated at N = 256 plus Wigner
 noise per stream seed, resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant pass kernel,
-timed with HIP events inside the timed region; `cpu_baseline` is the numpy
-oracle (a port of the reference algorithm) timed on this host on one stream.
+timed with HIP events inside the timed region; `cpu_baseline` is the C/OpenMP
+port of the reference algorithm (oracle/sp_cpu.c) timed on this host on one stream.
 """
 import argparse
 import json
@@ -38,25 +38,27 @@ B_ALG_PASS = 32.0 / 3.0        # one axis pass is a third of a transform under t
 B_MOVED_PASS = 32.0            # what a pass kernel actually reads + writes per cell (complex128 in, complex128 out)
 
 
-def cpu_baseline(size, seconds_cap=40.0):
-    """Oracle (numpy port of the reference step) on one stream of the same workload."""
+def cpu_baseline(size, seconds_cap=30.0):
+    """C port of the reference step (oracle/sp_cpu.c, OpenMP) on one stream of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import sp_oracle as o  # checker / baseline leg only
+    import sp_cpu          # checker / baseline leg only
+    import sp_oracle as o  # ICs for that leg
 
-    toml = dict(PLANE, sim_name="cpu", dims=3, size=size, ics=dict(type="none"))
-    params = list(o.simulation_iter(toml))[-1]
-    psi = o.sample_quantum_perturbation(o.plane_wave_ics(size), params.dx, 3, params.total_mass,
-                                        params.particle_mass, "Wigner", 1)
-    sim = o.SimulationObject(params, psi=psi)
-    sim.update()  # includes the one-off psi_k = F psi
+    base = {k: v for k, v in PLANE.items() if k != "ntot"}
+    sim = sp_cpu.CpuSim(size, **base)
+    psi = o.sample_quantum_perturbation(o.plane_wave_ics(size), 60.0 / size, 3, PLANE["total_mass"],
+                                        PLANE["total_mass"] / PLANE["ntot"], "Wigner", 1)
+    sim.set_psi(psi)
+    sim.update()  # warm-up; includes the one-off psi_k = F psi
     t0 = time.perf_counter()
     steps = 0
-    while steps < 2 and time.perf_counter() - t0 < seconds_cap / 2:
+    while steps < 20 and time.perf_counter() - t0 < seconds_cap / 2:
         sim.update()
         steps += 1
     dt = time.perf_counter() - t0
-    return dict(value=size ** 3 * steps / dt, unit="stream-cell updates/s", cores=1, kind="port",
-                sample=f"{size}^3 fp64, 1 stream, {steps} timed steps (numpy oracle, single thread)",
+    return dict(value=size ** 3 * steps / dt, unit="stream-cell updates/s", cores=sim.threads, kind="port",
+                sample=f"{size}^3 fp64, 1 stream, {steps} timed steps of the C/OpenMP restatement of the "
+                       f"reference algorithm (not ArrayFire), {sim.threads} threads",
                 seconds=round(dt, 2))
 
 
