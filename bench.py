@@ -35,7 +35,13 @@ PLANE = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=64
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 B_ALG_STEP = 224.0             # algorithmic bytes per stream-cell update, fp64: 7 transforms x (16 B in + 16 B out)
 B_ALG_PASS = 32.0 / 3.0        # one axis pass is a third of a transform under the same model
-B_MOVED_PASS = 32.0            # what a pass kernel actually reads + writes per cell (complex128 in, complex128 out)
+# pass kind -> (axis passes it performs per stream-cell, bytes it reads + writes per stream-cell)
+KINDS = {
+    "psi_inv_z": (1, 32.0), "psi_inv_y": (1, 32.0), "psi_invx_rho": (2, 32.0),   # 16 in + 8 W out (+16 psi out in the first half)
+    "psi_fwd_x": (1, 40.0), "psi_fwd_y": (1, 32.0), "psi_fwdz_invz": (2, 48.0),
+    "w_fwd_y": (1, 16.0), "poisson_z": (2, 16.0), "w_inv_y": (1, 16.0), "phi_inv_x": (1, 12.0),
+    "rho_fwd_x": (1, 24.0), "plain": (1, 32.0),
+}
 
 
 def cpu_baseline(size, seconds_cap=30.0):
@@ -112,12 +118,13 @@ def main():
         work = [None, None]
 
     def one_step(i):
-        ev.update()
         if world > 1:
             b = i & 1
             if work[b] is not None:
                 work[b].wait()
-            ev.density_sum(dens[b].data_ptr())
+            ev.step_density(dens[b].data_ptr())                 # the step leaves sum_s |psi_s|^2 here
+        ev.update()
+        if world > 1:
             work[b] = dist.all_reduce(dens[b], async_op=True)   # sum over ranks; mean = / streams
         ev.sync()                                               # per-step status (dt, dump flags) on the host
 
@@ -158,16 +165,17 @@ def main():
             raise SystemExit(f"invalid run: {steps_done} of {args.steps} steps done, {aliased} streams aliased")
         value = n3 * args.streams * args.steps / elapsed
         # dominant kernel = the pass kind with the largest total time
+        prof = {k: v for k, v in prof.items() if v[1] > 0}
         kind, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
-        pair = kind in ("w_fwd_y", "poisson_z", "w_inv_y")         # these work on one complex grid per stream PAIR
-        cells_per_launch = n3 * min(args.batch, n_local) * (0.5 if pair else 1.0)
+        npass, moved = KINDS[kind]
+        cells_per_launch = n3 * min(args.batch, n_local)           # stream-cells one launch processes
         avg_s = kms / kcnt / 1e3
-        achieved = B_ALG_PASS * cells_per_launch / avg_s / 1e9
+        achieved = npass * B_ALG_PASS * cells_per_launch / avg_s / 1e9
         roofline = dict(bound="hbm", kernel=kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=moved * cells_per_launch,
                         avg_launch_ms=round(kms / kcnt, 4), launches=int(kcnt),
-                        alg_bytes_per_launch=B_ALG_PASS * cells_per_launch,
-                        moved_gbs=round(B_MOVED_PASS * cells_per_launch / avg_s / 1e9, 1),
+                        alg_bytes_per_launch=npass * B_ALG_PASS * cells_per_launch,
+                        moved_gbs=round(moved * cells_per_launch / avg_s / 1e9, 1),
                         step_alg_gbs=round(value * B_ALG_STEP / world / 1e9, 1),
                         step_frac=round(value * B_ALG_STEP / world / 1e9 / HBM_PEAK_GBS, 4),
                         per_kind_ms={k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()})

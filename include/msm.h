@@ -101,6 +101,8 @@ const char* msm_last_error(const msm_ctx* ctx);   /* ctx may be NULL: last creat
 int32_t msm_get_derived(const msm_ctx* ctx, double out[8]);
 
 /* Initial conditions.
+ * All three are only valid before the first step (afterwards the state lives in
+ * Fourier space and they return MSM_ERR_STATE).
  * msm_set_psi: upload one stream's wavefunction from two host planes of T
  *   (what user_specified_ics builds from the npz members `real`/`imag`,
  *   simulator/src/ics.rs:716-726, and what every IC builder ends with).
@@ -114,7 +116,8 @@ int32_t msm_copy_psi(msm_ctx* ctx, int32_t dst_stream, int32_t src_stream);
 int32_t msm_sample(msm_ctx* ctx, int32_t stream, int32_t scheme, uint64_t seed);
 
 /* Unitary FFT of one stream's psi buffer in place, scale 1/N^{dims/2} in both
- * directions (utils/fft.rs:6-98: forward/inverse/forward_inplace/inverse_inplace). */
+ * directions (utils/fft.rs:6-98: forward/inverse/forward_inplace/inverse_inplace).
+ * Only before the first step. */
 int32_t msm_fft(msm_ctx* ctx, int32_t stream, int32_t direction);
 
 /* calculate_potential (simulation_object.rs:1066-1110) for streams
@@ -142,8 +145,9 @@ int32_t msm_sync(msm_ctx* ctx);
 int32_t msm_get_status(msm_ctx* ctx, msm_stream_status* out, int32_t n);
 
 /* Downloads (replace Array::host in complex_array_to_disk, utils/io.rs:46-47).
- * psi / psi_k: two planes of T; potential: one plane of T, valid for the
- * streams of the most recent msm_potential / step batch. */
+ * psi / psi_k: two planes of T; after the first step psi is rebuilt as
+ * F^-1[psi_k] (simulation_object.rs:581) for the download.  potential: one
+ * plane of T, the kick potential of the most recent msm_potential / step batch. */
 int32_t msm_get_psi(msm_ctx* ctx, int32_t stream, void* re, void* im);
 int32_t msm_get_psik(msm_ctx* ctx, int32_t stream, void* re, void* im);
 int32_t msm_get_potential(msm_ctx* ctx, int32_t stream, void* phi);
@@ -153,6 +157,10 @@ int32_t msm_get_potential(msm_ctx* ctx, int32_t stream, void* phi);
  * RCCL).  In-situ form of the synthesizer's psi2 accumulation
  * (synthesizer/src/lib.rs:217-229); it never feeds back into the evolution. */
 int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64);
+/* Fast path of the same product: register a DEVICE buffer of N^dims doubles (NULL to stop);
+ * every following step zeroes it and leaves in it the sum of |psi_s(t + dt)|^2 over the
+ * streams it advanced, accumulated inside the step's last pass at no extra HBM read. */
+int32_t msm_step_density(msm_ctx* ctx, void* device_out_f64);
 
 /* Timing helper for benchmarks: HIP events on the context's stream. */
 int32_t msm_timer_start(msm_ctx* ctx);

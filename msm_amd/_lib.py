@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
+# MSM_HIP_LIB selects another build of the same library (kernel-variant experiments)
+LIB_PATH = os.environ.get("MSM_HIP_LIB") or os.path.join(_HERE, "libmsm_hip.so")
 
 MSM_F64, MSM_F32 = 0, 1
 MSM_POISSON, MSM_WIGNER, MSM_HUSIMI = 0, 1, 2
@@ -64,6 +65,7 @@ SYMBOLS = {
     "msm_get_psik": (C.c_int32, [_P, C.c_int32, _P, _P]),
     "msm_get_potential": (C.c_int32, [_P, C.c_int32, _P]),
     "msm_density_sum": (C.c_int32, [_P, _P]),
+    "msm_step_density": (C.c_int32, [_P, _P]),
     "msm_timer_start": (C.c_int32, [_P]),
     "msm_timer_stop_ms": (C.c_int32, [_P, C.POINTER(C.c_float)]),
     "msm_profile": (C.c_int32, [_P, C.c_int32]),

@@ -131,6 +131,10 @@ int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64) {
     MSM_CHECK_CTX(ctx);
     return ctx->eng->density_sum(device_out_f64, ctx->err);
 }
+int32_t msm_step_density(msm_ctx* ctx, void* device_out_f64) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->step_density(device_out_f64, ctx->err);
+}
 int32_t msm_timer_start(msm_ctx* ctx) {
     MSM_CHECK_CTX(ctx);
     return ctx->eng->timer_start(ctx->err);
@@ -149,9 +153,9 @@ int32_t msm_profile_report(msm_ctx* ctx, int32_t max_kinds, double* total_ms, in
     return ctx->eng->profile_report(max_kinds, total_ms, (long long*)launches, n_kinds, ctx->err);
 }
 const char* msm_profile_kind_name(int32_t kind) {
-    static const char* names[] = {"psi_inv_x", "psi_inv_y", "psi_inv_z", "psi_fwd_x", "psi_fwd_y", "psi_fwd_z",
-                                  "rho_fwd_x", "w_fwd_y", "poisson_z", "w_inv_y", "phi_inv_x"};
-    return (kind >= 0 && kind < 11) ? names[kind] : "";
+    static const char* names[] = {"psi_inv_z", "psi_inv_y", "psi_invx_rho", "psi_fwd_x", "psi_fwd_y", "psi_fwdz_invz",
+                                  "w_fwd_y", "poisson_z", "w_inv_y", "phi_inv_x", "rho_fwd_x", "plain"};
+    return (kind >= 0 && kind < 12) ? names[kind] : "";
 }
 
 }  // extern "C"

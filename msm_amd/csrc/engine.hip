@@ -2,14 +2,18 @@
 // translation unit (-DMSM_REAL=double|float -DMSM_SUFFIX=f64|f32).
 //
 // Device layout (per context):
-//   X[n_streams][N^3]  complex  psi   (real space)       simulation_object.rs:57
-//   K[n_streams][N^3]  complex  psi_k (Fourier space)    simulation_object.rs:60
+//   P[n_streams][N^3]  complex  the state: psi before the first step, psi_k
+//                               afterwards                 simulation_object.rs:57,60
+//   X[batch][N^3]      complex  psi of the current batch inside a step (scratch)
 //   W[batch/2][N^3]    complex  Poisson work array: two streams' densities
 //                               packed as re/im of one complex grid
 //   PHI[batch][N^3]    real     potential per stream     simulation_object.rs:63
 // A 3-D transform is three passes of the batched line FFT (fft_core.hpp), one
 // per axis, each moving every element once HBM -> registers -> HBM; all
-// pointwise operators of the step are applied inside a pass's load or store.
+// pointwise operators of the step are applied inside a pass's load or store,
+// and neighbouring passes that work on the same lines are fused (forward z +
+// inverse z around the second drift; inverse x + density + Poisson forward x).
+// Between steps only psi_k is kept; psi is rebuilt on demand for downloads.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
@@ -49,7 +53,8 @@ struct State {
     real* kick;                     // phase per unit phi of the kick: -dt/hbar_ (static)
     real* a_now;                    // expanding: scale factor at step start
     real* tau_next;                 // expanding: tau to next dump
-    unsigned long long* maxphi;     // bits of (double) max|phi|, >= 0
+    unsigned long long* maxphi;     // bits of (double) max|phi| of psi(t), >= 0
+    double* maxphi_step;            // the value that sized the last timestep
     double* alias_sum;
     int* active;
     int* dump;
@@ -108,7 +113,7 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 // axis removed.
 template <int N, int AX>
 struct Tile {
-    using G = Geom<N>;
+    using G = Geom<N, AX>;
     int ln, j0, c1, c2;
     size_t base, stride;
     __device__ __forceinline__ Tile(int tile, int tid) {
@@ -143,9 +148,9 @@ struct Tile {
     }
 };
 
-template <int N>
+template <int N, int AX>
 __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
-    using G = Geom<N>;
+    using G = Geom<N, AX>;
     if constexpr (G::USES_LDS) {
         for (int i = threadIdx.x; i < N; i += G::THREADS) tw_lds[i] = tw_g[i];
         // visibility: the first use is after the stage-0 exchange barrier
@@ -153,55 +158,52 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
 }
 
 // ---------------------------------------------------------------------------
-// psi passes: every transform of psi / psi_k and the plain passes on W
+// generic axis pass: transforms of psi / psi_k and the plain passes on W
 // ---------------------------------------------------------------------------
 struct PsiArgs {
     const cplx* src;
     cplx* dst;
     size_t n3;
     const int* active;   // may be null
-    int s0;              // first stream of this launch
+    int s0;              // first (global) stream of this launch
+    int src_local;       // 1: src is indexed by blockIdx.y (batch scratch), 0: by the global stream id
+    int dst_local;
     int pair_nb;         // > 0: blockIdx.y is a PAIR index over nb streams (W passes)
     const cplx* tw;
-    const cplx* drift;
+    const cplx* drift;   // [n_streams][N]
     const real* phi;     // [batch][n3], local stream index
-    const real* kick;
+    const real* kick;    // [n_streams]
     real scale;
-    double* alias_sum;
-    const real* ksq;
-    real alias_cut, fourpi2;
 };
 
-// LOAD: 0 plain, 1 multiply by the drift table at the line position,
-//       2 kick psi *= exp(i kick phi)       (simulation_object.rs:535-545)
-// STORE: 0 scale only, 1 drift table times scale (simulation_object.rs:562-574),
-//        2 as 1 plus the aliased-mass sum     (simulation_object.rs:1249-1280)
+// LOAD: 0 plain, 1 multiply by the drift table at the line position (simulation_object.rs:504-516),
+//       2 kick psi *= exp(i kick phi)                                 (simulation_object.rs:535-545)
+// STORE: 0 scale only, 1 drift table times scale                      (simulation_object.rs:562-574)
 template <int N, int SGN, int AX, int LOAD, int STORE>
-__global__ __launch_bounds__(Geom<N>::THREADS) void k_psi_pass(PsiArgs a) {
-    using G = Geom<N>;
+__global__ __launch_bounds__((Geom<N, AX>::THREADS)) void k_psi_pass(PsiArgs a) {
+    using G = Geom<N, AX>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
-    __shared__ double red[STORE == 2 ? G::THREADS : 1];
 
     const int ls = blockIdx.y;
-    int s = a.s0 + ls;
+    const int sg = a.s0 + ls;  // global stream id (per-stream tables, activity)
+    int si = a.src_local ? ls : sg, di = a.dst_local ? ls : sg;
     if (a.pair_nb > 0) {
         const int sa = a.s0 + 2 * ls, sb = sa + 1;
         const bool act = a.active == nullptr || a.active[sa] || (2 * ls + 1 < a.pair_nb && a.active[sb]);
         if (!act) return;
-        s = ls;  // W is indexed by the local pair
-    } else if (a.active != nullptr && !a.active[s]) {
+        si = di = ls;  // W is indexed by the local pair
+    } else if (a.active != nullptr && !a.active[sg]) {
         return;
     }
-    const int sg = a.s0 + ls;  // global stream id for per-stream tables
 
     const Tile<N, AX> t(blockIdx.x, threadIdx.x);
     cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N>(tw, a.tw);
+    load_twiddles<N, AX>(tw, a.tw);
     cplx* line = lds + t.ln * G::LINE_LDS;
 
-    const cplx* __restrict__ src = a.src + (size_t)s * a.n3;
-    cplx* __restrict__ dst = a.dst + (size_t)s * a.n3;
+    const cplx* __restrict__ src = a.src + (size_t)si * a.n3;
+    cplx* __restrict__ dst = a.dst + (size_t)di * a.n3;
 
     cplx v[E];
 #pragma unroll
@@ -227,27 +229,76 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_psi_pass(PsiArgs a) {
 
     LineFft<real, N, SGN>::run(v, t.j0, line, tw);
 
-    double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int pos = t.j0 + TPL * q;
         cplx val = v[q];
         if constexpr (STORE >= 1) val = cmul(val, a.drift[(size_t)sg * N + pos]);
-        val = cscale(val, a.scale);
-        dst[t.base + (size_t)pos * t.stride] = val;
-        if constexpr (STORE == 2) {
-            // k^2 in the reference's association ((kx^2 + ky^2) + kz^2) * (2 pi)^2
-            real k2;
-            if constexpr (AX == 2) k2 = ((a.ksq[t.c1] + a.ksq[t.c2]) + a.ksq[pos]) * a.fourpi2;
-            else if constexpr (AX == 1) k2 = ((a.ksq[t.c1] + a.ksq[pos]) + a.ksq[t.c2]) * a.fourpi2;
-            else k2 = ((a.ksq[pos] + a.ksq[t.c1]) + a.ksq[t.c2]) * a.fourpi2;
-            if (k2 > a.alias_cut) acc += (double)(val.x * val.x + val.y * val.y);
-        }
+        dst[t.base + (size_t)pos * t.stride] = cscale(val, a.scale);
     }
-    if constexpr (STORE == 2) {
-        const double tot = block_sum<G::THREADS>(acc, red);
-        if (threadIdx.x == 0) atomicAdd(&a.alias_sum[sg], tot);
+}
+
+// ---------------------------------------------------------------------------
+// fused z pass around the second kinetic half-step:
+//   psi_k = D_z F_z[.] / N^{3/2}   -> stored (the state carried to the next step), aliased-mass sum,
+//   then straight on with F_z^{-1} of the same lines (first pass of psi = F^-1 psi_k).
+// (simulation_object.rs:552-581 and check_alias :1249-1280.)  Saves one read of psi_k.
+// ---------------------------------------------------------------------------
+struct FzArgs {
+    const cplx* X;       // [batch][n3] local: input (x and y already transformed) and output
+    cplx* Xout;
+    cplx* P;             // [n_streams][n3] global: psi_k
+    size_t n3;
+    const int* active;
+    int s0;
+    const cplx* tw;
+    const cplx* drift;
+    real scale;          // 1 / N^{dims/2}
+    const real* ksq;
+    real alias_cut, fourpi2;
+    double* partial;     // [n_streams][ntiles]
+    int ntiles;
+};
+
+template <int N>
+__global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_fwdz_invz(FzArgs a) {
+    using G = Geom<N, 2>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+    __shared__ double red[G::THREADS];
+
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    const Tile<N, 2> t(blockIdx.x, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N, 2>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+    const cplx* __restrict__ x = a.X + (size_t)ls * a.n3;
+    cplx* __restrict__ xo = a.Xout + (size_t)ls * a.n3;
+    cplx* __restrict__ pk = a.P + (size_t)sg * a.n3;
+    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = x[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
+    LineFft<real, N, -1>::run(v, t.j0, line, tw);
+
+    const real kxy = a.ksq[t.c1] + a.ksq[t.c2];  // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int pos = t.j0 + TPL * q;
+        v[q] = cscale(cmul(v[q], d[pos]), a.scale);
+        pk[t.base + (size_t)pos * t.stride] = v[q];
+        const real k2 = (kxy + a.ksq[pos]) * a.fourpi2;
+        if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
     }
+    const double tot = block_sum<G::THREADS>(acc, red);   // also orders the LDS reuse below
+    if (threadIdx.x == 0) a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
+
+    LineFft<real, N, +1>::run(v, t.j0, line, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) xo[t.base + (size_t)(t.j0 + TPL * q) * t.stride] = v[q];
 }
 
 // ---------------------------------------------------------------------------
@@ -256,23 +307,28 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_psi_pass(PsiArgs a) {
 // Green's function is real and even, so the inverse returns phi_a + i phi_b.
 // ---------------------------------------------------------------------------
 struct PoisArgs {
-    const cplx* X;       // [n_streams][n3]
+    const cplx* X;       // psi, [.][n3]
+    cplx* Xout;          // where the fused inverse pass stores psi (may alias X)
+    int x_local;         // 1: X is the batch scratch (local index), 0: the per-stream state
     cplx* W;             // [pairs][n3]
     real* PHI;           // [batch][n3]
     size_t n3;
     const int* active;
     int s0, nb;
     const cplx* tw;
+    const cplx* drift;
     const real* ksq;
-    real mass_factor, pois_c, fourpi2, inv_n3;
-    unsigned long long* maxphi;
+    real mass_factor, pois_c, fourpi2, inv_n3, scale;
+    double* partial;     // [n_streams][ntiles] per-workgroup max|phi|
+    int ntiles;
+    double* dens;        // optional [n3]: += sum over streams |psi|^2
 };
 
-// x-pass, forward: load rho = M |psi|^2 of both streams of the pair
+// x pass, forward, from a stored psi: rho = M |psi|^2 of both streams of the pair
 // (calculate_density, simulation_object.rs:1031-1063).
 template <int N>
-__global__ __launch_bounds__(Geom<N>::THREADS) void k_rho_pass(PoisArgs a) {
-    using G = Geom<N>;
+__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_rho_pass(PoisArgs a) {
+    using G = Geom<N, 0>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
     const int p = blockIdx.y;
@@ -282,11 +338,11 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_rho_pass(PoisArgs a) {
 
     const Tile<N, 0> t(blockIdx.x, threadIdx.x);
     cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N>(tw, a.tw);
+    load_twiddles<N, 0>(tw, a.tw);
     cplx* line = lds + t.ln * G::LINE_LDS;
 
-    const cplx* __restrict__ xa = a.X + (size_t)sa * a.n3;
-    const cplx* __restrict__ xb = a.X + (size_t)sb * a.n3;
+    const cplx* __restrict__ xa = a.X + (size_t)(a.x_local ? 2 * p : sa) * a.n3;
+    const cplx* __restrict__ xb = a.X + (size_t)(a.x_local ? 2 * p + 1 : sb) * a.n3;
     cplx* __restrict__ w = a.W + (size_t)p * a.n3;
 
     cplx v[E];
@@ -313,12 +369,85 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_rho_pass(PoisArgs a) {
     for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
 }
 
-// z-pass, fused: forward FFT, Green's multiply -C / k^2 with the k = 0 mode
+// Last pass of psi = F^-1[...] (along x) fused with the first pass of the Poisson solve:
+// for every pair of the batch, finish psi_a and psi_b (drift factor, inverse x transform, unitary
+// scale), optionally store them, form rho_a + i rho_b in registers and transform it along x into W.
+// One workgroup owns one tile of lines for ALL pairs, so the optional ensemble density
+// sum_s |psi_s|^2 is accumulated in registers and added to `dens` without atomics.
+template <int N, int DRIFT, int STOREPSI, int DENS>
+__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_invx_rho(PoisArgs a) {
+    using G = Geom<N, 0>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+
+    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N, 0>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+
+    double dacc[DENS ? E : 1];
+    if constexpr (DENS) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) dacc[q] = 0.0;
+    }
+    const int pairs = (a.nb + 1) / 2;
+    for (int p = 0; p < pairs; ++p) {
+        const int sa = a.s0 + 2 * p, sb = sa + 1;
+        const bool act_a = a.active[sa] != 0;
+        const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+        if (!act_a && !act_b) continue;   // uniform over the workgroup
+        real rho[2][E];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool act = h == 0 ? act_a : act_b;
+            if (act) {
+                const int sg = h == 0 ? sa : sb;
+                const cplx* __restrict__ x = a.X + (size_t)(2 * p + h) * a.n3;
+                cplx v[E];
+#pragma unroll
+                for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
+                if constexpr (DRIFT) {
+                    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+#pragma unroll
+                    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+                }
+                LineFft<real, N, +1>::run(v, t.j0, line, tw);
+                cplx* __restrict__ xo = a.Xout + (size_t)(2 * p + h) * a.n3;
+#pragma unroll
+                for (int q = 0; q < E; ++q) {
+                    v[q] = cscale(v[q], a.scale);
+                    if constexpr (STOREPSI) xo[t.base + t.j0 + TPL * q] = v[q];
+                    const real m2 = v[q].x * v[q].x + v[q].y * v[q].y;
+                    rho[h][q] = a.mass_factor * m2;
+                    if constexpr (DENS) dacc[q] += (double)m2;
+                }
+                if constexpr (G::USES_LDS) __syncthreads();   // exchange reads done before the next run writes
+            } else {
+#pragma unroll
+                for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
+            }
+        }
+        cplx v[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
+        LineFft<real, N, -1>::run(v, t.j0, line, tw);
+        cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+#pragma unroll
+        for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
+        if constexpr (G::USES_LDS) __syncthreads();
+    }
+    if constexpr (DENS) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];
+    }
+}
+
+// z pass, fused: forward FFT, Green's multiply -C / k^2 with the k = 0 mode
 // zeroed (simulation_object.rs:1076-1102), inverse FFT.  The unitary scales of
 // both 3-D transforms (1/N^3 in total, exact) ride on the Green's factor.
 template <int N>
-__global__ __launch_bounds__(Geom<N>::THREADS) void k_poisson_mid(PoisArgs a) {
-    using G = Geom<N>;
+__global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_poisson_mid(PoisArgs a) {
+    using G = Geom<N, 2>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
     const int p = blockIdx.y;
@@ -327,7 +456,7 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_poisson_mid(PoisArgs a) {
 
     const Tile<N, 2> t(blockIdx.x, threadIdx.x);
     cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N>(tw, a.tw);
+    load_twiddles<N, 2>(tw, a.tw);
     cplx* line = lds + t.ln * G::LINE_LDS;
     cplx* __restrict__ w = a.W + (size_t)p * a.n3;
 
@@ -349,11 +478,11 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_poisson_mid(PoisArgs a) {
     for (int q = 0; q < E; ++q) w[t.base + (size_t)(t.j0 + TPL * q) * t.stride] = v[q];
 }
 
-// x-pass, inverse: split phi_a / phi_b, track max|phi| per stream
-// (real(phi) simulation_object.rs:1109; max_all(abs(phi)) :905).
+// x pass, inverse: split phi_a / phi_b (real(phi), simulation_object.rs:1109) and/or
+// record this workgroup's max|phi| per stream (max_all(abs(phi)), :905).
 template <int N, int STOREPHI, int TRACKMAX>
-__global__ __launch_bounds__(Geom<N>::THREADS) void k_phi_out(PoisArgs a) {
-    using G = Geom<N>;
+__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
+    using G = Geom<N, 0>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
     __shared__ double red[TRACKMAX ? G::THREADS : 1];
@@ -364,7 +493,7 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_phi_out(PoisArgs a) {
 
     const Tile<N, 0> t(blockIdx.x, threadIdx.x);
     cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N>(tw, a.tw);
+    load_twiddles<N, 0>(tw, a.tw);
     cplx* line = lds + t.ln * G::LINE_LDS;
     const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
 
@@ -394,24 +523,37 @@ __global__ __launch_bounds__(Geom<N>::THREADS) void k_phi_out(PoisArgs a) {
         __syncthreads();
         const double rb = block_max<G::THREADS>(mb, red);
         if (threadIdx.x == 0) {
-            // non-negative doubles (and NaN, which sorts above them) order like their bit patterns
-            atomicMax(&a.maxphi[sa], (unsigned long long)__double_as_longlong(ra));
-            if (has_b) atomicMax(&a.maxphi[sb], (unsigned long long)__double_as_longlong(rb));
+            a.partial[(size_t)sa * a.ntiles + blockIdx.x] = ra;
+            if (has_b) a.partial[(size_t)sb * a.ntiles + blockIdx.x] = rb;
         }
+    }
+}
+
+// Reduce the per-workgroup partials of one stream in a fixed order (bitwise reproducible).
+// MODE 0: sum -> alias_sum;  MODE 1: max (NaN wins) -> maxphi bits.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reduce_partials(State st, const double* __restrict__ partial, int ntiles,
+                                                         int s0) {
+    __shared__ double red[256];
+    const int s = s0 + blockIdx.x;
+    if (!st.active[s]) return;
+    const double* __restrict__ p = partial + (size_t)s * ntiles;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < ntiles; i += 256) {
+        const double v = p[i];
+        if (MODE == 0) acc += v;
+        else acc = (v != v) ? v : ((acc != acc) ? acc : (v > acc ? v : acc));
+    }
+    const double r = MODE == 0 ? block_sum<256>(acc, red) : block_max<256>(acc, red);
+    if (threadIdx.x == 0) {
+        if (MODE == 0) st.alias_sum[s] = r;
+        else st.maxphi[s] = (unsigned long long)__double_as_longlong(r);
     }
 }
 
 // ---------------------------------------------------------------------------
 // scalar kernels: one thread per stream, arithmetic order of the reference
 // ---------------------------------------------------------------------------
-__global__ void k_zero_reductions(State st, int s0, int nb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb) {
-        st.maxphi[s0 + i] = 0ull;
-        st.alias_sum[s0 + i] = 0.0;
-    }
-}
-
 // get_timestep (simulation_object.rs:878-934; expanding :939-990)
 __global__ void k_timestep(State st, Consts c, int s0, int nb) {
 #pragma clang fp contract(off)
@@ -419,7 +561,9 @@ __global__ void k_timestep(State st, Consts c, int s0, int nb) {
     if (i >= nb) return;
     const int s = s0 + i;
     if (!st.active[s]) return;
-    const real pmax = (real)__longlong_as_double((long long)st.maxphi[s]);
+    const double pmax_d = __longlong_as_double((long long)st.maxphi[s]);
+    st.maxphi_step[s] = pmax_d;
+    const real pmax = (real)pmax_d;
     const real two = (real)2.0, twopi = (real)(2.0 * 3.14159265358979323846);
     real kinetic, potential, ttnd;
     if (c.expanding) {
@@ -484,13 +628,13 @@ __global__ void k_post_step(State st, Consts c, int s0, int nb, const real* new_
     st.active[s] = (!aliased && st.time[s] < c.tfinal) ? 1 : 0;
 }
 
-__global__ void k_publish(State st, Consts c, int ns) {
+__global__ void k_publish(State st, Consts c, int ns, int fresh_max) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns) return;
     msm_stream_status o;
     o.time = (double)st.time[s];
     o.dt = (double)st.dt[s];
-    o.max_phi = __longlong_as_double((long long)st.maxphi[s]);
+    o.max_phi = fresh_max ? __longlong_as_double((long long)st.maxphi[s]) : st.maxphi_step[s];
     o.alias_mass = (double)((real)st.alias_sum[s] * c.dkpow);
     o.tau = (double)st.tau[s];
     o.n_steps = st.nsteps[s];
@@ -555,9 +699,9 @@ __global__ void k_sample(cplx* __restrict__ psi, size_t n, unsigned long long se
 }
 
 // sum over streams of |psi_s|^2 (double accumulation)
-__global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, double* __restrict__ out) {
+__global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, double* __restrict__ out, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (size_t)gridDim.x * blockDim.x) {
-        double acc = 0.0;
+        double acc = accumulate ? out[i] : 0.0;
         for (int s = 0; s < ns; ++s) {
             const cplx v = X[(size_t)s * n3 + i];
             acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
@@ -589,11 +733,18 @@ bool dispatch_n(int N, F&& f) {
 // the engine
 // ---------------------------------------------------------------------------
 enum ProfKind {
-    PK_PSI_INV_X = 0, PK_PSI_INV_Y, PK_PSI_INV_Z,      // psi <- F^-1 psi_k passes (drift on load when stepping)
-    PK_PSI_FWD_X, PK_PSI_FWD_Y, PK_PSI_FWD_Z,          // psi_k <- F psi passes (x: kick on load; z: alias sum)
-    PK_RHO_X, PK_W_FWD_Y, PK_POISSON_Z, PK_W_INV_Y, PK_PHI_X,   // Poisson solve on stream pairs
+    PK_INV_Z = 0,     // psi_k -> scratch, drift on load, inverse z
+    PK_INV_Y,         // inverse y (drift on load in the first half of the step)
+    PK_INVX_RHO,      // inverse x + rho + forward x of the Poisson pair
+    PK_FWD_X,         // kick on load, forward x, drift on store
+    PK_FWD_Y,         // forward y, drift on store
+    PK_FWDZ_INVZ,     // forward z, drift, store psi_k, alias sum, inverse z
+    PK_W_FWD_Y, PK_POISSON_Z, PK_W_INV_Y, PK_PHI_X,   // Poisson solve on stream pairs
+    PK_RHO_X,         // rho from a stored psi (first step, msm_potential)
+    PK_PLAIN,         // plain transform passes (msm_fft, first psi_k, downloads)
     PK_COUNT
 };
+
 class Engine final : public IEngine {
   public:
     explicit Engine(const msm_config& cfg) : cfg_(cfg) {}
@@ -614,8 +765,11 @@ class Engine final : public IEngine {
     int get_psi(int s, void* re, void* im, bool kspace, std::string& err) override;
     int get_potential(int s, void* phi, std::string& err) override;
     int density_sum(void* dev_out, std::string& err) override;
+    int step_density(void* dev_out, std::string& err) override;
     int timer_start(std::string& err) override;
     int timer_stop(float* ms, std::string& err) override;
+    int profile(int enable, std::string& err) override;
+    int profile_report(int max_kinds, double* total_ms, long long* launches, int* n_kinds, std::string& err) override;
     void derived(double out[8]) const override {
         out[0] = (double)dx_; out[1] = (double)dx_; out[2] = (double)c_.k2max; out[3] = (double)c_.hbar;
         out[4] = cfg_.total_mass / cfg_.particle_mass;
@@ -629,32 +783,48 @@ class Engine final : public IEngine {
         if (s < 0 || s >= ns_) { err = "stream index out of range"; return MSM_ERR_INVALID; }
         return MSM_OK;
     }
-    // one axis pass of a psi-type transform
+    int need_real(std::string& err) const {
+        if (fourier_) { err = "the streams are already evolving (state is held in Fourier space)"; return MSM_ERR_STATE; }
+        return MSM_OK;
+    }
     template <int SGN, int LOAD, int STORE>
-    void launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind = -1);
-    // whole 3-D transforms
-    void fft3_plain(cplx* src, cplx* dst, int s0, int n, int sgn, const int* active);
-    void poisson(int s0, int nb, bool store_phi, bool track_max);
+    void launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind);
+    void fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn, const int* active);
+    PoisArgs pois_args(int s0, int nb) const;
+    void poisson_tail(int s0, int nb, bool store_phi, bool track_max);   // W passes after the fused/rho x pass
+    void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max);
+    void first_step_init(int s0, int nb);
     void step_front(int s0, int nb);
     void step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
-    void ensure_kspace(int s0, int nb);
-    void publish();
+    void publish(bool fresh_max = false);
+    template <typename F> void for_batches(F&& f) {
+        for (int s0 = 0; s0 < ns_; s0 += batch_) {
+            const int nb = std::min(batch_, ns_ - s0);
+            bool any = false;
+            for (int i = 0; i < nb; ++i) any = any || host_active_[s0 + i];
+            if (any) f(s0, nb);
+        }
+    }
 
     msm_config cfg_;
-    int N_ = 0, ns_ = 0, batch_ = 0, dims_ = 3;
+    int N_ = 0, ns_ = 0, batch_ = 0, dims_ = 3, ntiles_ = 0;
     size_t n3_ = 0;
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-    cplx *X_ = nullptr, *K_ = nullptr, *W_ = nullptr, *tw_ = nullptr;
+    cplx *P_ = nullptr;   // [n_streams][n3]: psi before the first step, psi_k afterwards
+    cplx *X_ = nullptr;   // [batch][n3]: psi of the batch inside a step
+    cplx *W_ = nullptr, *tw_ = nullptr;
     real *PHI_ = nullptr, *ksq_ = nullptr;
-    real *d_in_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // expanding per-step inputs
+    double* partial_ = nullptr;
+    double* step_dens_ = nullptr;   // caller-owned accumulation target, may be null
+    real* d_in_[3] = {nullptr, nullptr, nullptr};  // expanding per-step inputs
     State st_{};
     Consts c_{};
     real dx_ = 0, kinetic_dt_ = 0, comoving_box_ = 0;
     msm_stream_status* h_status_ = nullptr;
     std::vector<int> host_active_;
-    bool kspace_valid_ = false;
+    bool fourier_ = false;   // P_ holds psi_k (after the first step)
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
@@ -678,10 +848,6 @@ class Engine final : public IEngine {
         (void)hipEventRecord(r.b, stream_);
         prof_.push_back(r);
     }
-
-  public:
-    int profile(int enable, std::string& err) override;
-    int profile_report(int max_kinds, double* total_ms, long long* launches, int* n_kinds, std::string& err) override;
 };
 
 void Engine::release() {
@@ -695,6 +861,7 @@ void Engine::release() {
     ev_pool_.clear();
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
+    ev0_ = ev1_ = nullptr;
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
 }
@@ -719,9 +886,9 @@ int Engine::init(std::string& err) {
     HIP_TRY(hipEventCreate(&ev0_));
     HIP_TRY(hipEventCreate(&ev1_));
 
-    // sub-batch: bounded scratch (W + PHI = 2 real grids per stream), even count
+    // sub-batch: bounded scratch (X + W + PHI = 2 complex grids per stream), whole Poisson pairs
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
-    if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;   // whole Poisson pairs in every full batch
+    if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
@@ -772,6 +939,12 @@ int Engine::init(std::string& err) {
     c_.inv_n3 = (real)(1.0 / ((double)N_ * N_ * N_));
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
+    // per-workgroup partials: the x-pass and z-pass tilings may differ
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        ntiles_ = (int)std::max(n3_ / N / Geom<N, 0>::LPW, n3_ / N / Geom<N, 2>::LPW);
+    });
+
     // ---- device memory
     auto dmalloc = [&](void** p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes);
@@ -779,11 +952,12 @@ int Engine::init(std::string& err) {
         return e;
     };
     const size_t grid_bytes = n3_ * sizeof(cplx);
-    HIP_TRY(dmalloc((void**)&X_, grid_bytes * ns_));
-    HIP_TRY(dmalloc((void**)&K_, grid_bytes * ns_));
     const int pairs = (batch_ + 1) / 2;
+    HIP_TRY(dmalloc((void**)&P_, grid_bytes * ns_));
+    HIP_TRY(dmalloc((void**)&X_, grid_bytes * (size_t)(2 * pairs)));
     HIP_TRY(dmalloc((void**)&W_, grid_bytes * pairs));
     HIP_TRY(dmalloc((void**)&PHI_, n3_ * sizeof(real) * (size_t)(2 * pairs)));
+    HIP_TRY(dmalloc((void**)&partial_, sizeof(double) * (size_t)ns_ * ntiles_));
     HIP_TRY(dmalloc((void**)&tw_, sizeof(cplx) * N_));
     HIP_TRY(dmalloc((void**)&ksq_, sizeof(real) * N_));
     HIP_TRY(dmalloc((void**)&st_.time, sizeof(real) * ns_));
@@ -793,6 +967,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(dmalloc((void**)&st_.a_now, sizeof(real) * ns_));
     HIP_TRY(dmalloc((void**)&st_.tau_next, sizeof(real) * ns_));
     HIP_TRY(dmalloc((void**)&st_.maxphi, sizeof(unsigned long long) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.maxphi_step, sizeof(double) * ns_));
     HIP_TRY(dmalloc((void**)&st_.alias_sum, sizeof(double) * ns_));
     HIP_TRY(dmalloc((void**)&st_.active, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.dump, sizeof(int) * ns_));
@@ -827,6 +1002,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(hipMemcpy(st_.a_now, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.tau_next, zr.data(), sizeof(real) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(st_.maxphi, 0, sizeof(unsigned long long) * ns_));
+    HIP_TRY(hipMemset(st_.maxphi_step, 0, sizeof(double) * ns_));
     HIP_TRY(hipMemset(st_.alias_sum, 0, sizeof(double) * ns_));
     HIP_TRY(hipMemcpy(st_.active, ones.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.dump, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
@@ -834,125 +1010,177 @@ int Engine::init(std::string& err) {
     HIP_TRY(hipMemcpy(st_.aliased, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.nsteps, zl.data(), sizeof(long long) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.drift, one_c.data(), sizeof(cplx) * (size_t)ns_ * N_, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(X_, 0, grid_bytes * ns_));
-    HIP_TRY(hipMemset(K_, 0, grid_bytes * ns_));
+    HIP_TRY(hipMemset(P_, 0, grid_bytes * ns_));
     host_active_.assign(ns_, 1);
     publish();
     HIP_TRY(hipStreamSynchronize(stream_));
     return MSM_OK;
 }
 
-void Engine::publish() {
-    k_publish<<<(ns_ + 63) / 64, 64, 0, stream_>>>(st_, c_, ns_);
+void Engine::publish(bool fresh_max) {
+    k_publish<<<(ns_ + 63) / 64, 64, 0, stream_>>>(st_, c_, ns_, fresh_max ? 1 : 0);
     (void)hipMemcpyAsync(h_status_, st_.status, sizeof(msm_stream_status) * ns_, hipMemcpyDeviceToHost, stream_);
 }
 
 template <int SGN, int LOAD, int STORE>
 void Engine::launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind) {
-    if (kind < 0) kind = SGN > 0 ? (PK_PSI_INV_X + ax) : (PK_PSI_FWD_X + ax);
     timed(kind, [&] {
         dispatch_n(N_, [&](auto nc) {
             constexpr int N = decltype(nc)::value;
-            using G = Geom<N>;
-            const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)nblk_y);
-            const dim3 block(G::THREADS);
-            if (ax == 0) k_psi_pass<N, SGN, 0, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
-            else if (ax == 1) k_psi_pass<N, SGN, 1, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
-            else k_psi_pass<N, SGN, 2, LOAD, STORE><<<grid, block, 0, stream_>>>(a);
+            using G0 = Geom<N, 0>;
+            using GS = Geom<N, 1>;
+            const dim3 grid0((unsigned)(n3_ / N / G0::LPW), (unsigned)nblk_y), gridS((unsigned)(n3_ / N / GS::LPW), (unsigned)nblk_y);
+            if (ax == 0) k_psi_pass<N, SGN, 0, LOAD, STORE><<<grid0, dim3(G0::THREADS), 0, stream_>>>(a);
+            else if (ax == 1) k_psi_pass<N, SGN, 1, LOAD, STORE><<<gridS, dim3(GS::THREADS), 0, stream_>>>(a);
+            else k_psi_pass<N, SGN, 2, LOAD, STORE><<<gridS, dim3(GS::THREADS), 0, stream_>>>(a);
         });
     });
 }
 
-// unitary 3-D transform without pointwise work: first pass src -> dst, rest in place
-void Engine::fft3_plain(cplx* src, cplx* dst, int s0, int n, int sgn, const int* active) {
+// unitary 3-D transform without pointwise work: first pass src -> dst, rest in place on dst
+void Engine::fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn,
+                        const int* active) {
     PsiArgs a{};
     a.n3 = n3_; a.active = active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.scale = (real)1;
+    a.src = src; a.dst = dst; a.src_local = src_local; a.dst_local = dst_local;
     if (sgn < 0) {
-        a.src = src; a.dst = dst; launch_psi<-1, 0, 0>(0, a, n);
-        a.src = dst;              launch_psi<-1, 0, 0>(1, a, n);
-        a.scale = c_.unit_scale;  launch_psi<-1, 0, 0>(2, a, n);
+        launch_psi<-1, 0, 0>(0, a, n, PK_PLAIN);
+        a.src = dst; a.src_local = dst_local;
+        launch_psi<-1, 0, 0>(1, a, n, PK_PLAIN);
+        a.scale = c_.unit_scale;
+        launch_psi<-1, 0, 0>(2, a, n, PK_PLAIN);
     } else {
-        a.src = src; a.dst = dst; launch_psi<+1, 0, 0>(2, a, n);
-        a.src = dst;              launch_psi<+1, 0, 0>(1, a, n);
-        a.scale = c_.unit_scale;  launch_psi<+1, 0, 0>(0, a, n);
+        launch_psi<+1, 0, 0>(2, a, n, PK_PLAIN);
+        a.src = dst; a.src_local = dst_local;
+        launch_psi<+1, 0, 0>(1, a, n, PK_PLAIN);
+        a.scale = c_.unit_scale;
+        launch_psi<+1, 0, 0>(0, a, n, PK_PLAIN);
     }
 }
 
-void Engine::poisson(int s0, int nb, bool store_phi, bool track_max) {
-    const int pairs = (nb + 1) / 2;
+PoisArgs Engine::pois_args(int s0, int nb) const {
     PoisArgs p{};
-    p.X = X_; p.W = W_; p.PHI = PHI_; p.n3 = n3_; p.active = st_.active; p.s0 = s0; p.nb = nb;
-    p.tw = tw_; p.ksq = ksq_; p.mass_factor = c_.mass_factor; p.pois_c = c_.pois_c; p.fourpi2 = c_.fourpi2;
-    p.inv_n3 = c_.inv_n3; p.maxphi = st_.maxphi;
+    p.X = X_; p.Xout = X_; p.x_local = 1; p.W = W_; p.PHI = PHI_; p.n3 = n3_; p.active = st_.active;
+    p.s0 = s0; p.nb = nb; p.tw = tw_; p.drift = st_.drift; p.ksq = ksq_; p.mass_factor = c_.mass_factor;
+    p.pois_c = c_.pois_c; p.fourpi2 = c_.fourpi2; p.inv_n3 = c_.inv_n3; p.scale = c_.unit_scale;
+    p.partial = partial_; p.ntiles = ntiles_; p.dens = nullptr;
+    return p;
+}
+
+// y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
+void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max) {
+    const int pairs = (nb + 1) / 2;
+    const PoisArgs p = pois_args(s0, nb);
     PsiArgs a{};
     a.src = W_; a.dst = W_; a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = nb; a.tw = tw_; a.scale = (real)1;
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
-        using G = Geom<N>;
-        const dim3 grid((unsigned)(n3_ / N / G::LPW), (unsigned)pairs);
-        const dim3 block(G::THREADS);
-        timed(PK_RHO_X, [&] { k_rho_pass<N><<<grid, block, 0, stream_>>>(p); });
-        timed(PK_W_FWD_Y, [&] { k_psi_pass<N, -1, 1, 0, 0><<<grid, block, 0, stream_>>>(a); });
-        timed(PK_POISSON_Z, [&] { k_poisson_mid<N><<<grid, block, 0, stream_>>>(p); });
-        timed(PK_W_INV_Y, [&] { k_psi_pass<N, +1, 1, 0, 0><<<grid, block, 0, stream_>>>(a); });
+        using G0 = Geom<N, 0>;
+        using GS = Geom<N, 1>;
+        const dim3 grid0((unsigned)(n3_ / N / G0::LPW), (unsigned)pairs), gridS((unsigned)(n3_ / N / GS::LPW), (unsigned)pairs);
+        const dim3 block0(G0::THREADS), blockS(GS::THREADS);
+        timed(PK_W_FWD_Y, [&] { k_psi_pass<N, -1, 1, 0, 0><<<gridS, blockS, 0, stream_>>>(a); });
+        timed(PK_POISSON_Z, [&] { k_poisson_mid<N><<<gridS, blockS, 0, stream_>>>(p); });
+        timed(PK_W_INV_Y, [&] { k_psi_pass<N, +1, 1, 0, 0><<<gridS, blockS, 0, stream_>>>(a); });
         timed(PK_PHI_X, [&] {
-            if (store_phi && track_max) k_phi_out<N, 1, 1><<<grid, block, 0, stream_>>>(p);
-            else if (store_phi) k_phi_out<N, 1, 0><<<grid, block, 0, stream_>>>(p);
-            else k_phi_out<N, 0, 1><<<grid, block, 0, stream_>>>(p);
+            if (store_phi && track_max) k_phi_out<N, 1, 1><<<grid0, block0, 0, stream_>>>(p);
+            else if (store_phi) k_phi_out<N, 1, 0><<<grid0, block0, 0, stream_>>>(p);
+            else k_phi_out<N, 0, 1><<<grid0, block0, 0, stream_>>>(p);
         });
     });
+    if (track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0);
     if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
-// psi_k = F[psi] before the first step (simulation_object.rs:477-479)
-void Engine::ensure_kspace(int s0, int nb) { fft3_plain(X_, K_, s0, nb, -1, st_.active); }
+// whole Poisson solve from a psi that sits in memory
+void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max) {
+    PoisArgs p = pois_args(s0, nb);
+    p.X = X; p.x_local = local ? 1 : 0;
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using G0 = Geom<N, 0>;
+        const dim3 grid0((unsigned)(n3_ / N / G0::LPW), (unsigned)((nb + 1) / 2));
+        timed(PK_RHO_X, [&] { k_rho_pass<N><<<grid0, dim3(G0::THREADS), 0, stream_>>>(p); });
+    });
+    poisson_tail(s0, nb, store_phi, track_max);
+}
 
-// potential at t and the timestep (simulation_object.rs:497-500)
+// Before the first step P_ holds psi: size the first timestep from it (simulation_object.rs:497)
+// and move the state to Fourier space (psi_k = F psi, :477-479).
+void Engine::first_step_init(int s0, int nb) {
+    poisson_from_psi(P_, false, s0, nb, false, true);
+    fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
+}
+
+// timestep (simulation_object.rs:500); max|phi| of psi(t) was left by the previous step's tail
 void Engine::step_front(int s0, int nb) {
-    k_zero_reductions<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, s0, nb);
-    poisson(s0, nb, false, true);
     k_timestep<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb);
 }
 
-// drift/2, F^-1, potential, kick, F, drift/2, F^-1, bookkeeping (:504-635)
+// drift/2, F^-1, potential, kick, F, drift/2, F^-1, bookkeeping, potential for the next dt (:504-635, :497)
 void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau) {
     k_drift_table<<<dim3((N_ + 63) / 64, nb), 64, 0, stream_>>>(st_, c_, ksq_, s0);
     PsiArgs a{};
     a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.drift = st_.drift;
-    a.phi = PHI_; a.kick = st_.kick; a.alias_sum = st_.alias_sum; a.ksq = ksq_; a.alias_cut = c_.alias_cut;
-    a.fourpi2 = c_.fourpi2; a.scale = (real)1;
-    // psi = F^-1[ D psi_k ]
-    a.src = K_; a.dst = X_; launch_psi<+1, 1, 0>(2, a, nb);
-    a.src = X_;             launch_psi<+1, 1, 0>(1, a, nb);
-    a.scale = c_.unit_scale; launch_psi<+1, 1, 0>(0, a, nb);
+    a.phi = PHI_; a.kick = st_.kick; a.scale = (real)1;
+    PoisArgs p = pois_args(s0, nb);
+
+    // psi = F^-1[ D psi_k ]  (z, y plain passes; x fused with rho and the Poisson forward x pass)
+    a.src = P_; a.src_local = 0; a.dst = X_; a.dst_local = 1;
+    launch_psi<+1, 1, 0>(2, a, nb, PK_INV_Z);
+    a.src = X_; a.src_local = 1;
+    launch_psi<+1, 1, 0>(1, a, nb, PK_INV_Y);
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using G0 = Geom<N, 0>;
+        timed(PK_INVX_RHO, [&] {
+            k_invx_rho<N, 1, 1, 0><<<dim3((unsigned)(n3_ / N / G0::LPW)), dim3(G0::THREADS), 0, stream_>>>(p);
+        });
+    });
     // phi at the half-drifted psi
-    poisson(s0, nb, true, false);   // max|phi| keeps the value that sized dt
-    // psi_k = D F[ kick psi ]
-    a.scale = (real)1;
-    a.src = X_; a.dst = X_;  launch_psi<-1, 2, 1>(0, a, nb);
-                             launch_psi<-1, 0, 1>(1, a, nb);
-    a.dst = K_; a.scale = c_.unit_scale; launch_psi<-1, 0, 2>(2, a, nb);
-    // psi = F^-1[ psi_k ]
-    a.scale = (real)1;
-    a.src = K_; a.dst = X_;  launch_psi<+1, 0, 0>(2, a, nb);
-    a.src = X_;              launch_psi<+1, 0, 0>(1, a, nb);
-    a.scale = c_.unit_scale; launch_psi<+1, 0, 0>(0, a, nb);
+    poisson_tail(s0, nb, true, false);
+    // psi_k = D F[ kick psi ], then on into psi = F^-1[ psi_k ]
+    launch_psi<-1, 2, 1>(0, a, nb, PK_FWD_X);
+    launch_psi<-1, 0, 1>(1, a, nb, PK_FWD_Y);
+    FzArgs f{};
+    f.X = X_; f.Xout = X_; f.P = P_; f.n3 = n3_; f.active = st_.active; f.s0 = s0; f.tw = tw_; f.drift = st_.drift;
+    f.scale = c_.unit_scale; f.ksq = ksq_; f.alias_cut = c_.alias_cut; f.fourpi2 = c_.fourpi2;
+    f.partial = partial_; f.ntiles = ntiles_;
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using GS = Geom<N, 2>;
+        timed(PK_FWDZ_INVZ, [&] {
+            k_fwdz_invz<N><<<dim3((unsigned)(n3_ / N / GS::LPW), (unsigned)nb), dim3(GS::THREADS), 0, stream_>>>(f);
+        });
+    });
+    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0);
     k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+    // streams that are still running: finish psi(t + dt) only as far as the next step needs it,
+    // i.e. its density (and the ensemble density if asked for); psi itself is not written back
+    launch_psi<+1, 0, 0>(1, a, nb, PK_INV_Y);
+    p.dens = step_dens_;
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using G0 = Geom<N, 0>;
+        const dim3 grid((unsigned)(n3_ / N / G0::LPW)), block(G0::THREADS);
+        timed(PK_INVX_RHO, [&] {
+            if (step_dens_) k_invx_rho<N, 0, 0, 1><<<grid, block, 0, stream_>>>(p);
+            else k_invx_rho<N, 0, 0, 0><<<grid, block, 0, stream_>>>(p);
+        });
+    });
+    poisson_tail(s0, nb, false, true);
 }
 
 int Engine::step(std::string& err) {
     if (cfg_.expanding) { err = "expanding contexts step with msm_step_begin / msm_step_end"; return MSM_ERR_STATE; }
     if (in_step_) { err = "msm_step inside an open msm_step_begin"; return MSM_ERR_STATE; }
-    for (int s0 = 0; s0 < ns_; s0 += batch_) {
-        const int nb = std::min(batch_, ns_ - s0);
-        bool any = false;
-        for (int i = 0; i < nb; ++i) any = any || host_active_[s0 + i];
-        if (!any) continue;
-        if (!kspace_valid_) ensure_kspace(s0, nb);
+    if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
+    for_batches([&](int s0, int nb) {
+        if (!fourier_) first_step_init(s0, nb);
         step_front(s0, nb);
         step_back(s0, nb, nullptr, nullptr, nullptr);
-    }
-    kspace_valid_ = true;
+    });
+    fourier_ = true;
     publish();
     HIP_TRY(hipGetLastError());
     return MSM_OK;
@@ -968,8 +1196,8 @@ int Engine::step_begin(const double* a_now, const double* tau_next, std::string&
     HIP_TRY(hipMemcpyAsync(st_.a_now, a.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(st_.tau_next, t.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));  // the host vectors die here
-    if (!kspace_valid_) ensure_kspace(0, ns_);
-    kspace_valid_ = true;
+    if (!fourier_) first_step_init(0, ns_);
+    fourier_ = true;
     step_front(0, ns_);
     publish();
     in_step_ = true;
@@ -994,6 +1222,7 @@ int Engine::step_end(const double* kick_a, const double* new_time, const double*
     HIP_TRY(hipMemcpyAsync(d_in_[1], ntau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(d_in_[2], stau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
     step_back(0, ns_, d_in_[0], d_in_[1], d_in_[2]);
     publish();
     in_step_ = false;
@@ -1010,6 +1239,7 @@ int Engine::sync(std::string& err) {
 int Engine::get_status(msm_stream_status* out, int n, std::string& err) {
     if (!out || n < 0 || n > ns_) { err = "bad status buffer"; return MSM_ERR_INVALID; }
     HIP_TRY(hipStreamSynchronize(stream_));
+    for (int s = 0; s < ns_; ++s) host_active_[s] = h_status_[s].active;
     std::memcpy(out, h_status_, sizeof(msm_stream_status) * n);
     return MSM_OK;
 }
@@ -1017,46 +1247,51 @@ int Engine::get_status(msm_stream_status* out, int n, std::string& err) {
 int Engine::potential(int first, int count, std::string& err) {
     if (first < 0 || count < 1 || first + count > ns_) { err = "stream range out of bounds"; return MSM_ERR_INVALID; }
     if (count > 2 * ((batch_ + 1) / 2)) { err = "count exceeds the batch size"; return MSM_ERR_INVALID; }
-    k_zero_reductions<<<(count + 63) / 64, 64, 0, stream_>>>(st_, first, count);
-    poisson(first, count, true, true);
-    publish();
+    if (in_step_) { err = "msm_potential inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    if (fourier_) {
+        fft3_plain(P_, false, X_, true, first, count, +1, nullptr);
+        poisson_from_psi(X_, true, first, count, true, true);
+    } else {
+        poisson_from_psi(P_, false, first, count, true, true);
+    }
+    publish(true);
     HIP_TRY(hipGetLastError());
     return MSM_OK;
 }
 
 int Engine::fft(int s, int dir, std::string& err) {
     if (int rc = check_stream(s, err)) return rc;
+    if (int rc = need_real(err)) return rc;
     if (dir != MSM_FORWARD && dir != MSM_INVERSE) { err = "direction must be -1 or +1"; return MSM_ERR_INVALID; }
-    fft3_plain(X_, X_, s, 1, dir, nullptr);
-    kspace_valid_ = false;
+    fft3_plain(P_, false, P_, false, s, 1, dir, nullptr);
     HIP_TRY(hipGetLastError());
     return MSM_OK;
 }
 
 int Engine::set_psi(int s, const void* re, const void* im, std::string& err) {
     if (int rc = check_stream(s, err)) return rc;
+    if (int rc = need_real(err)) return rc;
     if (!re || !im) { err = "null plane"; return MSM_ERR_INVALID; }
-    // stage the two planes in this stream's (not yet meaningful) psi_k slot halves
-    real* stage = (real*)(K_ + (size_t)s * n3_);
+    real* stage = (real*)X_;   // two real planes fit one complex scratch grid
     HIP_TRY(hipMemcpyAsync(stage, re, sizeof(real) * n3_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(stage + n3_, im, sizeof(real) * n3_, hipMemcpyHostToDevice, stream_));
-    k_interleave<<<2048, 256, 0, stream_>>>(X_ + (size_t)s * n3_, stage, stage + n3_, n3_);
+    k_interleave<<<2048, 256, 0, stream_>>>(P_ + (size_t)s * n3_, stage, stage + n3_, n3_);
     HIP_TRY(hipStreamSynchronize(stream_));
-    kspace_valid_ = false;
     return MSM_OK;
 }
 
 int Engine::copy_psi(int dst, int src, std::string& err) {
     if (int rc = check_stream(dst, err)) return rc;
     if (int rc = check_stream(src, err)) return rc;
+    if (int rc = need_real(err)) return rc;
     if (dst == src) return MSM_OK;
-    HIP_TRY(hipMemcpyAsync(X_ + (size_t)dst * n3_, X_ + (size_t)src * n3_, sizeof(cplx) * n3_, hipMemcpyDeviceToDevice, stream_));
-    kspace_valid_ = false;
+    HIP_TRY(hipMemcpyAsync(P_ + (size_t)dst * n3_, P_ + (size_t)src * n3_, sizeof(cplx) * n3_, hipMemcpyDeviceToDevice, stream_));
     return MSM_OK;
 }
 
 int Engine::sample(int s, int scheme, uint64_t seed, std::string& err) {
     if (int rc = check_stream(s, err)) return rc;
+    if (int rc = need_real(err)) return rc;
     if (scheme != MSM_WIGNER && scheme != MSM_HUSIMI) {
         err = "only Wigner and Husimi sampling are reproducible (the reference's Poisson branch uses thread_rng)";
         return MSM_ERR_INVALID;
@@ -1065,8 +1300,7 @@ int Engine::sample(int s, int scheme, uint64_t seed, std::string& err) {
     const real sqrt_n = (real)std::sqrt(n);
     const real sqrt_dv = std::sqrt(std::pow(dx_, (real)dims_));  // ics.rs:479-489
     const real div = scheme == MSM_WIGNER ? sqrt_n * (real)2.0 : sqrt_n * std::sqrt((real)2.0);
-    k_sample<<<2048, 256, 0, stream_>>>(X_ + (size_t)s * n3_, n3_, (unsigned long long)seed, sqrt_dv, div);
-    kspace_valid_ = false;
+    k_sample<<<2048, 256, 0, stream_>>>(P_ + (size_t)s * n3_, n3_, (unsigned long long)seed, sqrt_dv, div);
     HIP_TRY(hipGetLastError());
     return MSM_OK;
 }
@@ -1074,10 +1308,15 @@ int Engine::sample(int s, int scheme, uint64_t seed, std::string& err) {
 int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
     if (int rc = check_stream(s, err)) return rc;
     if (!re || !im) { err = "null plane"; return MSM_ERR_INVALID; }
-    if (kspace && !kspace_valid_) { err = "psi_k is only defined after the first step"; return MSM_ERR_STATE; }
-    const cplx* src = (kspace ? K_ : X_) + (size_t)s * n3_;
-    // split into W (free between steps) and copy the planes out
-    real* stage = (real*)W_;
+    if (in_step_) { err = "download inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    if (kspace && !fourier_) { err = "psi_k is only defined after the first step"; return MSM_ERR_STATE; }
+    const cplx* src = P_ + (size_t)s * n3_;
+    if (!kspace && fourier_) {
+        // psi = F^-1 psi_k (simulation_object.rs:581), materialised on demand in the batch scratch
+        fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
+        src = X_;
+    }
+    real* stage = (real*)W_;   // two real planes fit one complex scratch grid
     k_split<<<2048, 256, 0, stream_>>>(src, stage, stage + n3_, n3_);
     HIP_TRY(hipMemcpyAsync(re, stage, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(im, stage + n3_, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
@@ -1099,8 +1338,23 @@ int Engine::get_potential(int s, void* phi, std::string& err) {
 
 int Engine::density_sum(void* dev_out, std::string& err) {
     if (!dev_out) { err = "null output"; return MSM_ERR_INVALID; }
-    k_density_sum<<<2048, 256, 0, stream_>>>(X_, n3_, ns_, (double*)dev_out);
+    if (in_step_) { err = "msm_density_sum inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    if (!fourier_) {
+        k_density_sum<<<2048, 256, 0, stream_>>>(P_, n3_, ns_, (double*)dev_out, 0);
+    } else {
+        for (int s0 = 0; s0 < ns_; s0 += batch_) {
+            const int nb = std::min(batch_, ns_ - s0);
+            fft3_plain(P_, false, X_, true, s0, nb, +1, nullptr);
+            k_density_sum<<<2048, 256, 0, stream_>>>(X_, n3_, nb, (double*)dev_out, s0 > 0 ? 1 : 0);
+        }
+    }
     HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::step_density(void* dev_out, std::string& err) {
+    (void)err;
+    step_dens_ = (double*)dev_out;
     return MSM_OK;
 }
 

@@ -24,6 +24,7 @@ struct IEngine {
     virtual int get_psi(int s, void* re, void* im, bool kspace, std::string& err) = 0;
     virtual int get_potential(int s, void* phi, std::string& err) = 0;
     virtual int density_sum(void* dev_out, std::string& err) = 0;
+    virtual int step_density(void* dev_out, std::string& err) = 0;
     virtual int timer_start(std::string& err) = 0;
     virtual int timer_stop(float* ms, std::string& err) = 0;
     virtual int profile(int enable, std::string& err) = 0;

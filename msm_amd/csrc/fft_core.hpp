@@ -87,11 +87,20 @@ template <> struct Plan<128>  { static constexpr int E = 16, S = 2, R0 = 16, R1 
 template <> struct Plan<256>  { static constexpr int E = 16, S = 2, R0 = 16, R1 = 16, R2 = 1; };
 template <> struct Plan<512>  { static constexpr int E = 16, S = 3, R0 = 16, R1 = 16, R2 = 2; };
 
-template <int N> struct Geom {
+// Lines per workgroup: MSM_LPW_X for passes along the contiguous axis, MSM_LPW_S for the
+// strided axes (there LPW neighbouring lines make each global row segment LPW*sizeof(complex) bytes).
+#ifndef MSM_LPW_X
+#define MSM_LPW_X 16
+#endif
+#ifndef MSM_LPW_S
+#define MSM_LPW_S 16
+#endif
+template <int N, int AX> struct Geom {
     using P = Plan<N>;
     static constexpr int E = P::E;
     static constexpr int TPL = N / E;                  // threads per line
-    static constexpr int LPW = N < 16 ? N : 16;        // lines per workgroup
+    static constexpr int LPW0 = AX == 0 ? MSM_LPW_X : MSM_LPW_S;
+    static constexpr int LPW = N < LPW0 ? N : LPW0;    // lines per workgroup
     static constexpr int THREADS = TPL * LPW;
     static constexpr int LINE_LDS = N + (N >> 4) + 1;  // padded line length in LDS (elements)
     static constexpr bool USES_LDS = P::S > 1;
@@ -108,8 +117,7 @@ __device__ __forceinline__ int lds_pad(int p) { return p + (p >> 4); }
 template <typename T, int N, int SGN>
 struct LineFft {
     using P = Plan<N>;
-    using G = Geom<N>;
-    static constexpr int E = P::E, TPL = G::TPL;
+    static constexpr int E = P::E, TPL = N / E;
 
     template <int SIDX, int NS>
     static __device__ __forceinline__ void stage(cx<T> (&v)[E], int j0, cx<T>* line, const cx<T>* tw) {

@@ -176,6 +176,9 @@ class Evolver:
     def density_sum(self, device_ptr: int):
         self._check(self._lib.msm_density_sum(self._ctx, device_ptr), "msm_density_sum")
 
+    def step_density(self, device_ptr):
+        self._check(self._lib.msm_step_density(self._ctx, device_ptr), "msm_step_density")
+
     def timer_start(self):
         self._check(self._lib.msm_timer_start(self._ctx), "msm_timer_start")
 
