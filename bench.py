@@ -37,9 +37,10 @@ B_ALG_STEP = 224.0             # algorithmic bytes per stream-cell update, fp64:
 B_ALG_PASS = 32.0 / 3.0        # one axis pass is a third of a transform under the same model
 # pass kind -> (axis passes it performs per stream-cell, bytes it reads + writes per stream-cell)
 KINDS = {
-    "psi_inv_z": (1, 32.0), "psi_inv_y": (1, 32.0), "psi_invx_rho": (2, 32.0),   # 16 in + 8 W out (+16 psi out in the first half)
-    "psi_fwd_x": (1, 40.0), "psi_fwd_y": (1, 32.0), "psi_fwdz_invz": (2, 48.0),
-    "w_fwd_y": (1, 16.0), "poisson_z": (2, 16.0), "w_inv_y": (1, 16.0), "phi_inv_x": (1, 12.0),
+    "psi_inv_z": (1, 32.0), "psi_inv_y": (1, 32.0), "psi_invx_rho": (2, 24.0),   # 16 psi in + 8 W out
+    "psi_fwd_x": (2, 40.0),                                                      # 8 W in + 16 in + 16 out
+    "psi_fwd_y": (1, 32.0), "psi_fwdz_invz": (2, 48.0),
+    "w_fwd_y": (1, 16.0), "poisson_z": (2, 16.0), "w_inv_y": (1, 16.0), "phi_inv_x": (1, 8.0),
     "rho_fwd_x": (1, 24.0), "plain": (1, 32.0),
 }
 

@@ -75,7 +75,37 @@ struct Consts {
 // ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
+// sin/cos of a kick phase in double: three-term Cody-Waite reduction by pi/2 (33-bit pieces, the
+// products k*piece are exact for |k| < 2^20) and the fdlibm minimax kernels on [-pi/4, pi/4].
+// About 1 ulp for |x| < 1e6; beyond that the error grows like the spacing of doubles at x.
+// Far fewer registers and instructions than the general-purpose library routine, which carries a
+// Payne-Hanek path the bounded kick phase never needs.
+__device__ __forceinline__ void sincos_t(double x, double* s, double* c) {
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624871116645580e-21, r);
+    r = fma(-k, 8.47842766036889956997e-32, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w1 = 1.0 - hz;
+    const double cs = w1 + (((1.0 - w1) - hz) + z * z * pc);
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
 __device__ __forceinline__ void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 
 template <int THREADS>
@@ -442,6 +472,68 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_invx_rho(PoisArgs a) 
     }
 }
 
+// Kick pass, fused with the last pass of the Poisson solve and the first pass of psi_k = F[psi]:
+// per pair, phi_a + i phi_b = F_x^-1[W] stays in registers; then for each stream the half-drifted
+// psi is rebuilt from the y-transformed scratch exactly as k_invx_rho formed it (drift factor,
+// inverse x, unitary scale), kicked psi *= exp(i kick phi) (simulation_object.rs:535-545),
+// transformed forward along x and stored with the second drift's x factor (:562-574).
+// Neither phi nor the half-drifted psi ever goes to HBM.
+template <int N>
+__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a, const real* __restrict__ kick) {
+    using G = Geom<N, 0>;
+    constexpr int E = G::E, TPL = G::TPL;
+    __shared__ cplx lds[G::LDS_ELEMS];
+    // one workgroup per (tile, stream); the two streams of a pair sit in neighbouring workgroups so
+    // that the second read of the pair's W tile is served on-chip
+    const int ls = 2 * blockIdx.y + (blockIdx.x & 1);
+    if (ls >= a.nb) return;
+    const int sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    const int h = ls & 1, p = ls >> 1;
+
+    const Tile<N, 0> t(blockIdx.x >> 1, threadIdx.x);
+    cplx* tw = lds + G::LPW * G::LINE_LDS;
+    load_twiddles<N, 0>(tw, a.tw);
+    cplx* line = lds + t.ln * G::LINE_LDS;
+    const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+    cplx* __restrict__ x = a.Xout + (size_t)ls * a.n3;
+    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+    const real kc = kick[sg];
+
+    real phi[E];
+    {
+        cplx vw[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
+        LineFft<real, N, +1>::run(vw, t.j0, line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            // select on VALUES: a select between two elements of the register array would turn into a
+            // runtime-indexed access and push the whole array to scratch memory
+            real re = vw[q].x, im = vw[q].y;
+            asm volatile("" : "+v"(re), "+v"(im));
+            phi[q] = h == 0 ? re : im;
+        }
+    }
+    if constexpr (G::USES_LDS) __syncthreads();   // also keeps the psi loads below the phi transform
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+    LineFft<real, N, +1>::run(v, t.j0, line, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        real sn, cs;
+        sincos_t(kc * phi[q], &sn, &cs);
+        v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
+    }
+    if constexpr (G::USES_LDS) __syncthreads();
+    LineFft<real, N, -1>::run(v, t.j0, line, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
+}
+
 // z pass, fused: forward FFT, Green's multiply -C / k^2 with the k = 0 mode
 // zeroed (simulation_object.rs:1076-1102), inverse FFT.  The unitary scales of
 // both 3-D transforms (1/N^3 in total, exact) ride on the Green's factor.
@@ -791,7 +883,8 @@ class Engine final : public IEngine {
     void launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind);
     void fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn, const int* active);
     PoisArgs pois_args(int s0, int nb) const;
-    void poisson_tail(int s0, int nb, bool store_phi, bool track_max);   // W passes after the fused/rho x pass
+    // W passes after the fused/rho x pass; with_x = false leaves F_y,z-inverted W for a fused consumer
+    void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true);
     void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max);
     void first_step_init(int s0, int nb);
     void step_front(int s0, int nb);
@@ -1068,7 +1161,7 @@ PoisArgs Engine::pois_args(int s0, int nb) const {
 }
 
 // y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
-void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max) {
+void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x) {
     const int pairs = (nb + 1) / 2;
     const PoisArgs p = pois_args(s0, nb);
     PsiArgs a{};
@@ -1082,14 +1175,14 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max) {
         timed(PK_W_FWD_Y, [&] { k_psi_pass<N, -1, 1, 0, 0><<<gridS, blockS, 0, stream_>>>(a); });
         timed(PK_POISSON_Z, [&] { k_poisson_mid<N><<<gridS, blockS, 0, stream_>>>(p); });
         timed(PK_W_INV_Y, [&] { k_psi_pass<N, +1, 1, 0, 0><<<gridS, blockS, 0, stream_>>>(a); });
-        timed(PK_PHI_X, [&] {
+        if (with_x) timed(PK_PHI_X, [&] {
             if (store_phi && track_max) k_phi_out<N, 1, 1><<<grid0, block0, 0, stream_>>>(p);
             else if (store_phi) k_phi_out<N, 1, 0><<<grid0, block0, 0, stream_>>>(p);
             else k_phi_out<N, 0, 1><<<grid0, block0, 0, stream_>>>(p);
         });
     });
-    if (track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0);
-    if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
+    if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0);
+    if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
 // whole Poisson solve from a psi that sits in memory
@@ -1134,13 +1227,19 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         timed(PK_INVX_RHO, [&] {
-            k_invx_rho<N, 1, 1, 0><<<dim3((unsigned)(n3_ / N / G0::LPW)), dim3(G0::THREADS), 0, stream_>>>(p);
+            k_invx_rho<N, 1, 0, 0><<<dim3((unsigned)(n3_ / N / G0::LPW)), dim3(G0::THREADS), 0, stream_>>>(p);
         });
     });
-    // phi at the half-drifted psi
-    poisson_tail(s0, nb, true, false);
+    // phi at the half-drifted psi, left as F_x[phi_a + i phi_b] in W
+    poisson_tail(s0, nb, false, false, false);
     // psi_k = D F[ kick psi ], then on into psi = F^-1[ psi_k ]
-    launch_psi<-1, 2, 1>(0, a, nb, PK_FWD_X);
+    dispatch_n(N_, [&](auto nc) {
+        constexpr int N = decltype(nc)::value;
+        using G0 = Geom<N, 0>;
+        timed(PK_FWD_X, [&] {
+            k_kick_fwdx<N><<<dim3((unsigned)(2 * (n3_ / N / G0::LPW)), (unsigned)((nb + 1) / 2)), dim3(G0::THREADS), 0, stream_>>>(p, st_.kick);
+        });
+    });
     launch_psi<-1, 0, 1>(1, a, nb, PK_FWD_Y);
     FzArgs f{};
     f.X = X_; f.Xout = X_; f.P = P_; f.n3 = n3_; f.active = st_.active; f.s0 = s0; f.tw = tw_; f.drift = st_.drift;
@@ -1174,6 +1273,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
 int Engine::step(std::string& err) {
     if (cfg_.expanding) { err = "expanding contexts step with msm_step_begin / msm_step_end"; return MSM_ERR_STATE; }
     if (in_step_) { err = "msm_step inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    phi_s0_ = -1;   // the batch potential buffer is not maintained by steps
     if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
     for_batches([&](int s0, int nb) {
         if (!fourier_) first_step_init(s0, nb);
@@ -1222,6 +1322,7 @@ int Engine::step_end(const double* kick_a, const double* new_time, const double*
     HIP_TRY(hipMemcpyAsync(d_in_[1], ntau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(d_in_[2], stau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    phi_s0_ = -1;
     if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
     step_back(0, ns_, d_in_[0], d_in_[1], d_in_[2]);
     publish();

@@ -2,7 +2,7 @@
 
 Run from the repo root:  python tests/golden/make_golden.py
 Each file holds psi0 and, after steps 1, 2 and 10 of the split-step update,
-psi, the potential used for the kick, and the per-step scalars (dt, dump flag,
+psi, calculate_potential(psi), and the per-step scalars (dt, dump flag,
 alias mass, max|phi|, time).  Inputs are the reference's own example
 parameters (examples/spherical-tophat.toml, tomls/planeWave3d_e10_sym.toml)
 at reduced grid sizes.
@@ -37,7 +37,8 @@ def run(toml, size, which, dtype, nsteps=10, keep=(1, 2, 10)):
                      float(info["max_phi"]), float(info["time"])])
         if i in keep:
             out[f"psi_{i}"] = sim.psi.copy()
-            out[f"phi_{i}"] = sim.phi.copy()
+            # potential of the new psi, as the reference's dump recomputes it (simulation_object.rs:1167-1168)
+            out[f"phi_{i}"] = sim.calculate_potential().copy()
     out["scalars"] = np.array(scal)
     out["seed"] = np.array(-1 if params.sampling is None else params.sampling[0])
     return out

@@ -57,6 +57,7 @@ def test_golden_vectors(name, golden_dir):
         assert abs(info["alias_mass"] - alias) <= max(1e-4 * alias, 1e-20)
         if f"psi_{i}" in g:
             assert rel(sim.get_psi(), g[f"psi_{i}"]) < 1e-11
+            sim.potential()
             assert rel(sim.get_phi(), g[f"phi_{i}"]) < 1e-11
 
 

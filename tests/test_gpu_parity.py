@@ -186,6 +186,7 @@ def test_golden_vectors(name, golden_dir):
             assert abs(st.alias_mass - alias) <= max(1e-4 * alias, 1e-12 if f32 else 1e-20)
             if f"psi_{i}" in g:
                 assert rel_err(ev.get_psi(0), g[f"psi_{i}"]) < tol, i
+                ev.calculate_potential(0, 1)    # as dump() does with output_potential (simulation_object.rs:1167-1168)
                 assert rel_err(ev.get_potential(0), g[f"phi_{i}"]) < (2e-4 if f32 else 1e-11), i
 
 
