@@ -68,6 +68,16 @@ int main(int argc, char** argv) {
     RUN(0, 73984, 512) RUN(1, 73984, 512) RUN(2, 73984, 512)
     RUN(0, 39000, 1024) RUN(1, 39000, 1024) RUN(2, 39000, 1024)
     RUN(0, 0, 2048) RUN(1, 0, 2048) RUN(2, 0, 2048)
+    // working-set sweep: in-place y-pattern tile pass over buffers of growing size (Infinity Cache reach)
+    for (double mib : {32.0, 64.0, 128.0, 192.0, 256.0, 384.0, 512.0, 1024.0, 4096.0}) {
+        const long tiles = (long)(mib * 1048576.0 / 65536.0);      // one tile = 64 KiB
+        const long tot = tiles < total ? tiles : total;
+        const double g2 = 2.0 * tot * 65536.0 / 1e9;
+        float ms = timeit([&] { k_tile<1, 73984><<<tot, 256>>>(a, a, ntiles, tot); }, 20);
+        printf("in-place ax=1 working set %6.0f MiB: %.4f ms  %.0f GB/s\n", mib, ms, g2 / ms * 1e3);
+        ms = timeit([&] { k_tile<2, 73984><<<tot, 256>>>(a, a, ntiles, tot); }, 20);
+        printf("in-place ax=2 working set %6.0f MiB: %.4f ms  %.0f GB/s\n", mib, ms, g2 / ms * 1e3);
+    }
     // in place
     { float ms = timeit([&] { k_tile<1, 73984><<<total, 256>>>(a, a, ntiles, total); });
       printf("tile ax=1 in place lds=73984: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3); }
