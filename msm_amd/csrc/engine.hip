@@ -625,10 +625,10 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
 // MODE 0: sum -> alias_sum;  MODE 1: max (NaN wins) -> maxphi bits.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce_partials(State st, const double* __restrict__ partial, int ntiles,
-                                                         int s0) {
+                                                         int s0, const int* __restrict__ active) {
     __shared__ double red[256];
     const int s = s0 + blockIdx.x;
-    if (!st.active[s]) return;
+    if (!active[s]) return;
     const double* __restrict__ p = partial + (size_t)s * ntiles;
     double acc = 0.0;
     for (int i = threadIdx.x; i < ntiles; i += 256) {
@@ -882,10 +882,11 @@ class Engine final : public IEngine {
     template <int SGN, int LOAD, int STORE>
     void launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind);
     void fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn, const int* active);
-    PoisArgs pois_args(int s0, int nb) const;
+    PoisArgs pois_args(int s0, int nb, const int* act) const;
     // W passes after the fused/rho x pass; with_x = false leaves F_y,z-inverted W for a fused consumer
-    void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true);
-    void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max);
+    void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
+    // act = all_active_ solves for finished streams too (standalone msm_potential)
+    void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act);
     void first_step_init(int s0, int nb);
     void step_front(int s0, int nb);
     void step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
@@ -910,6 +911,7 @@ class Engine final : public IEngine {
     cplx *W_ = nullptr, *tw_ = nullptr;
     real *PHI_ = nullptr, *ksq_ = nullptr;
     double* partial_ = nullptr;
+    int* all_active_ = nullptr;     // [n_streams] of ones
     double* step_dens_ = nullptr;   // caller-owned accumulation target, may be null
     real* d_in_[3] = {nullptr, nullptr, nullptr};  // expanding per-step inputs
     State st_{};
@@ -1063,6 +1065,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(dmalloc((void**)&st_.maxphi_step, sizeof(double) * ns_));
     HIP_TRY(dmalloc((void**)&st_.alias_sum, sizeof(double) * ns_));
     HIP_TRY(dmalloc((void**)&st_.active, sizeof(int) * ns_));
+    HIP_TRY(dmalloc((void**)&all_active_, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.dump, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.dumps, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.aliased, sizeof(int) * ns_));
@@ -1098,6 +1101,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(hipMemset(st_.maxphi_step, 0, sizeof(double) * ns_));
     HIP_TRY(hipMemset(st_.alias_sum, 0, sizeof(double) * ns_));
     HIP_TRY(hipMemcpy(st_.active, ones.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(all_active_, ones.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.dump, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.dumps, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.aliased, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
@@ -1151,9 +1155,9 @@ void Engine::fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_loc
     }
 }
 
-PoisArgs Engine::pois_args(int s0, int nb) const {
+PoisArgs Engine::pois_args(int s0, int nb, const int* act) const {
     PoisArgs p{};
-    p.X = X_; p.Xout = X_; p.x_local = 1; p.W = W_; p.PHI = PHI_; p.n3 = n3_; p.active = st_.active;
+    p.X = X_; p.Xout = X_; p.x_local = 1; p.W = W_; p.PHI = PHI_; p.n3 = n3_; p.active = act;
     p.s0 = s0; p.nb = nb; p.tw = tw_; p.drift = st_.drift; p.ksq = ksq_; p.mass_factor = c_.mass_factor;
     p.pois_c = c_.pois_c; p.fourpi2 = c_.fourpi2; p.inv_n3 = c_.inv_n3; p.scale = c_.unit_scale;
     p.partial = partial_; p.ntiles = ntiles_; p.dens = nullptr;
@@ -1161,11 +1165,12 @@ PoisArgs Engine::pois_args(int s0, int nb) const {
 }
 
 // y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
-void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x) {
+void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x, const int* act) {
+    if (!act) act = st_.active;
     const int pairs = (nb + 1) / 2;
-    const PoisArgs p = pois_args(s0, nb);
+    const PoisArgs p = pois_args(s0, nb, act);
     PsiArgs a{};
-    a.src = W_; a.dst = W_; a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = nb; a.tw = tw_; a.scale = (real)1;
+    a.src = W_; a.dst = W_; a.n3 = n3_; a.active = act; a.s0 = s0; a.pair_nb = nb; a.tw = tw_; a.scale = (real)1;
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
@@ -1181,13 +1186,13 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
             else k_phi_out<N, 0, 1><<<grid0, block0, 0, stream_>>>(p);
         });
     });
-    if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0);
+    if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0, act);
     if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
 // whole Poisson solve from a psi that sits in memory
-void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max) {
-    PoisArgs p = pois_args(s0, nb);
+void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act) {
+    PoisArgs p = pois_args(s0, nb, act);
     p.X = X; p.x_local = local ? 1 : 0;
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
@@ -1195,13 +1200,13 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
         const dim3 grid0((unsigned)(n3_ / N / G0::LPW), (unsigned)((nb + 1) / 2));
         timed(PK_RHO_X, [&] { k_rho_pass<N><<<grid0, dim3(G0::THREADS), 0, stream_>>>(p); });
     });
-    poisson_tail(s0, nb, store_phi, track_max);
+    poisson_tail(s0, nb, store_phi, track_max, true, act);
 }
 
 // Before the first step P_ holds psi: size the first timestep from it (simulation_object.rs:497)
 // and move the state to Fourier space (psi_k = F psi, :477-479).
 void Engine::first_step_init(int s0, int nb) {
-    poisson_from_psi(P_, false, s0, nb, false, true);
+    poisson_from_psi(P_, false, s0, nb, false, true, st_.active);
     fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
 }
 
@@ -1216,7 +1221,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     PsiArgs a{};
     a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.drift = st_.drift;
     a.phi = PHI_; a.kick = st_.kick; a.scale = (real)1;
-    PoisArgs p = pois_args(s0, nb);
+    PoisArgs p = pois_args(s0, nb, st_.active);
 
     // psi = F^-1[ D psi_k ]  (z, y plain passes; x fused with rho and the Poisson forward x pass)
     a.src = P_; a.src_local = 0; a.dst = X_; a.dst_local = 1;
@@ -1252,7 +1257,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
             k_fwdz_invz<N><<<dim3((unsigned)(n3_ / N / GS::LPW), (unsigned)nb), dim3(GS::THREADS), 0, stream_>>>(f);
         });
     });
-    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0);
+    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0, st_.active);
     k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
     // streams that are still running: finish psi(t + dt) only as far as the next step needs it,
     // i.e. its density (and the ensemble density if asked for); psi itself is not written back
@@ -1289,16 +1294,17 @@ int Engine::step(std::string& err) {
 int Engine::step_begin(const double* a_now, const double* tau_next, std::string& err) {
     if (!cfg_.expanding) { err = "msm_step_begin is for expanding contexts"; return MSM_ERR_STATE; }
     if (in_step_) { err = "msm_step_begin called twice"; return MSM_ERR_STATE; }
-    if (ns_ > batch_) { err = "expanding contexts need batch_streams >= n_streams"; return MSM_ERR_STATE; }
     if (!a_now || !tau_next) { err = "null input"; return MSM_ERR_INVALID; }
     std::vector<real> a(ns_), t(ns_);
     for (int s = 0; s < ns_; ++s) { a[s] = (real)a_now[s]; t[s] = (real)tau_next[s]; }
     HIP_TRY(hipMemcpyAsync(st_.a_now, a.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(st_.tau_next, t.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));  // the host vectors die here
-    if (!fourier_) first_step_init(0, ns_);
+    for_batches([&](int s0, int nb) {
+        if (!fourier_) first_step_init(s0, nb);
+        step_front(s0, nb);
+    });
     fourier_ = true;
-    step_front(0, ns_);
     publish();
     in_step_ = true;
     HIP_TRY(hipGetLastError());
@@ -1324,7 +1330,7 @@ int Engine::step_end(const double* kick_a, const double* new_time, const double*
     HIP_TRY(hipStreamSynchronize(stream_));
     phi_s0_ = -1;
     if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
-    step_back(0, ns_, d_in_[0], d_in_[1], d_in_[2]);
+    for_batches([&](int s0, int nb) { step_back(s0, nb, d_in_[0], d_in_[1], d_in_[2]); });
     publish();
     in_step_ = false;
     HIP_TRY(hipGetLastError());
@@ -1351,9 +1357,9 @@ int Engine::potential(int first, int count, std::string& err) {
     if (in_step_) { err = "msm_potential inside an open msm_step_begin"; return MSM_ERR_STATE; }
     if (fourier_) {
         fft3_plain(P_, false, X_, true, first, count, +1, nullptr);
-        poisson_from_psi(X_, true, first, count, true, true);
+        poisson_from_psi(X_, true, first, count, true, true, all_active_);
     } else {
-        poisson_from_psi(P_, false, first, count, true, true);
+        poisson_from_psi(P_, false, first, count, true, true, all_active_);
     }
     publish(true);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,296 @@
+// msm-simulator: the reference's process surface (simulator/src/main.rs:9-89) on top of the
+// C ABI of include/msm.h.  TOML in, .npz initial conditions in, sim-data/{name}/psi_{k:05}_real|_imag
+// NPY dumps out.  Where the reference runs its N + 1 simulations one after the other
+// (main.rs:43-79), this driver advances them together in one device context.
+//
+//   msm-simulator --toml <path> [-v|--verbose] [--test]
+//                 [--expanding] [--precision f64|f32] [--device N] [--batch B]
+//
+// --expanding stands for the reference's cargo feature of the same name (compile-time there).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <future>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/msm.h"
+#include "cosmo.hpp"
+#include "ics.hpp"
+#include "npy_io.hpp"
+#include "params.hpp"
+
+using namespace msmhost;
+
+namespace {
+
+constexpr size_t MAX_CONCURRENT_GRID_WRITES = 16;   // simulation_object.rs:39 (x2 for real + imag)
+const char* SIM_DATA_FOLDER = "sim-data";           // simulation_object.rs:1116
+
+struct Args {
+    std::string toml;
+    bool verbose = false, test = false, expanding = false;
+    int precision = MSM_F64, device = 0, batch = 0;
+};
+
+[[noreturn]] void usage(const char* why) {
+    std::fprintf(stderr, "error: %s\n\nUSAGE:\n    msm-simulator [OPTIONS] --toml <TOML>\n\nOPTIONS:\n"
+                         "    -t, --toml <TOML>\n    -v, --verbose\n        --test\n        --expanding\n"
+                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n", why);
+    std::exit(2);
+}
+
+Args parse_args(int argc, char** argv) {
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        const std::string s = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) usage(("a value is required for '" + s + "'").c_str());
+            return argv[++i];
+        };
+        if (s == "--toml" || s == "-t") a.toml = val();
+        else if (s.rfind("--toml=", 0) == 0) a.toml = s.substr(7);
+        else if (s == "--verbose" || s == "-v") a.verbose = true;
+        else if (s == "--test") a.test = true;
+        else if (s == "--expanding") a.expanding = true;
+        else if (s == "--precision") { const std::string p = val(); if (p == "f64") a.precision = MSM_F64; else if (p == "f32") a.precision = MSM_F32; else usage("--precision takes f64 or f32"); }
+        else if (s == "--device") a.device = std::atoi(val().c_str());
+        else if (s == "--batch") a.batch = std::atoi(val().c_str());
+        else usage(("Found argument '" + s + "' which wasn't expected").c_str());
+    }
+    if (a.toml.empty()) usage("The following required arguments were not provided: --toml <TOML>");
+    return a;
+}
+
+void check(msm_ctx* ctx, int rc, const char* what) {
+    if (rc != MSM_OK) throw std::runtime_error(std::string(what) + " failed: " + msm_last_error(ctx));
+}
+
+// dump writers: two NPY files per array, written on worker threads, at most 32 in flight
+// (utils/io.rs:34-88, simulation_object.rs:1123-1136)
+class DumpWriters {
+  public:
+    template <typename T>
+    void submit(const std::string& base, std::vector<T>&& re, std::vector<T>&& im, const std::vector<size_t>& shape) {
+        while (active_.size() >= MAX_CONCURRENT_GRID_WRITES * 2) drain(false);
+        auto task = [](std::string path, std::vector<T> data, std::vector<size_t> shp) { write_npy<T>(path, data.data(), shp); };
+        active_.push_back(std::async(std::launch::async, task, base + "_real", std::move(re), shape));
+        active_.push_back(std::async(std::launch::async, task, base + "_imag", std::move(im), shape));
+    }
+    void drain(bool all) {
+        for (size_t i = 0; i < active_.size();) {
+            if (all || active_[i].wait_for(std::chrono::milliseconds(all ? 0 : 10)) == std::future_status::ready) {
+                active_[i].get();   // rethrows a failed write
+                active_[i] = std::move(active_.back());
+                active_.pop_back();
+            } else {
+                ++i;
+            }
+        }
+    }
+
+  private:
+    std::vector<std::future<void>> active_;
+};
+
+template <typename T>
+int run(const Args& args) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const TomlParameters toml = read_toml(args.toml, args.expanding);
+    const std::vector<StreamSpec> streams = simulation_iter(toml);
+    const bool multi_stream = streams.size() - 1 > 1;   // SimulationIter::len() counts the seeds (io.rs:121-125)
+    const int ns = (int)streams.size();
+    double particle_mass, hbar_;
+    determine_pmass_hbar_(toml, particle_mass, hbar_);
+    if (toml.dims < 1 || toml.dims > 3) throw std::runtime_error("dims must be 1, 2 or 3");
+
+    msm_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (int32_t)sizeof cfg;
+    cfg.device = args.device;
+    cfg.dims = (int32_t)toml.dims;
+    cfg.size = (int32_t)toml.size;
+    cfg.precision = args.precision;
+    cfg.n_streams = ns;
+    cfg.batch_streams = args.batch;
+    cfg.expanding = args.expanding ? 1 : 0;
+    cfg.axis_length = toml.axis_length;
+    cfg.time = toml.time.value_or(0.0);
+    cfg.final_sim_time = toml.final_sim_time;
+    cfg.cfl = toml.cfl;
+    cfg.num_data_dumps = toml.num_data_dumps;
+    cfg.total_mass = toml.total_mass;
+    cfg.particle_mass = particle_mass;
+    cfg.hbar_ = hbar_;
+    cfg.k2_cutoff = toml.k2_cutoff;
+    cfg.alias_threshold = toml.alias_threshold;
+    if (args.expanding) {
+        cfg.omega_matter_now = toml.cosmology->omega_matter_now;
+        cfg.omega_radiation_now = toml.cosmology->omega_radiation_now;
+        cfg.h = toml.cosmology->h;
+        cfg.z0 = toml.cosmology->z0;
+        cfg.max_dloga = toml.cosmology->max_dloga.value_or(0.0);
+    }
+    msm_ctx* ctx = nullptr;
+    if (msm_create(&cfg, &ctx) != MSM_OK) throw std::runtime_error(std::string("msm_create failed: ") + msm_last_error(nullptr));
+
+    double derived[8];
+    check(ctx, msm_get_derived(ctx, derived), "msm_get_derived");
+    const T dx = (T)derived[0];
+    const size_t N = toml.size, n_cells = ipow(N, toml.dims);
+
+    // ---- initial conditions (simulation_object.rs:406-435)
+    Planes<T> ics;
+    switch (toml.ics.type) {
+        case IcsType::UserSpecified: ics = user_specified_ics<T>(toml.ics.path, toml.dims, N); break;
+        case IcsType::ColdGauss: ics = cold_gauss<T>(toml.ics.mean, toml.ics.std, dx, toml.dims, N); break;
+        case IcsType::SphericalTophat:
+            ics = spherical_tophat<T>((T)toml.axis_length, dx, toml.dims, N, toml.ics.radius, toml.ics.delta, toml.ics.slope);
+            break;
+        case IcsType::ColdGaussKSpace: throw std::runtime_error("ColdGaussKSpace initial conditions are not built yet");
+    }
+    check(ctx, msm_set_psi(ctx, 0, ics.re.data(), ics.im.data()), "msm_set_psi");
+    for (int s = 1; s < ns; ++s) check(ctx, msm_copy_psi(ctx, s, 0), "msm_copy_psi");
+    for (int s = 0; s < ns; ++s)
+        if (streams[s].sampled) check(ctx, msm_sample(ctx, s, (int)streams[s].scheme, streams[s].seed), "msm_sample");
+    check(ctx, msm_sync(ctx), "msm_sync");
+
+    if (args.verbose) {
+        for (const StreamSpec& sp : streams) {
+            std::printf("\n\nWorking on simulation %s\nSimulation Parameters\n%s\n", sp.sim_name.c_str(), std::string(40, '-').c_str());
+            std::printf("axis_length         = %.6e\n", toml.axis_length);
+            if (args.expanding) std::printf("comoving_boxsize    = %.6e\n", derived[6]);
+            std::printf("dx                  = %.6e\ncurrent_time        = %.6e\nfinal_sim_time      = %.6e\n", derived[0], cfg.time, toml.final_sim_time);
+            std::printf("cfl                 = %.6e\nnum_data_dumps      = %u\ntotal_mass          = %.6e\n", toml.cfl, toml.num_data_dumps, toml.total_mass);
+            std::printf("particle_mass       = %.6e\nhbar_               = %.6e\nsim_name            = %s\n", particle_mass, hbar_, sp.sim_name.c_str());
+            std::printf("k2_cutoff           = %.6e\nalias_threshold     = %.6e\nk2_max              = %.6e\n", toml.k2_cutoff, toml.alias_threshold, derived[2]);
+            std::printf("n_tot               = %.6e\ndims                = %zu\nsize                = %zu\n%s\n", derived[4], toml.dims, toml.size, std::string(40, '-').c_str());
+            if (sp.sampled) std::printf("\n[sampling_parameters]\nsampling_scheme     = %s\nseed                = %llu\n",
+                                        sp.scheme == SamplingScheme::Wigner ? "Wigner" : sp.scheme == SamplingScheme::Husimi ? "Husimi" : "Poisson",
+                                        (unsigned long long)sp.seed);
+            std::printf("Physical Constants\nHBAR = %.5e\nPOIS_CONSTANT = %.5e\n", HBAR, POIS_CONST);
+        }
+    }
+    if (args.test) { msm_destroy(ctx); return 0; }
+
+    // ---- dumps (simulation_object.rs:1113-1223)
+    std::vector<size_t> shape(4, 1);
+    for (size_t d = 0; d < toml.dims; ++d) shape[d] = N;
+    DumpWriters writers;
+    auto dump = [&](int s, int k) {
+        const std::string dir = std::string(SIM_DATA_FOLDER) + "/" + streams[s].sim_name;
+        std::filesystem::create_directories(dir);
+        char name[64];
+        std::snprintf(name, sizeof name, "/psi_%05d", k);
+        std::vector<T> re(n_cells), im(n_cells);
+        check(ctx, msm_get_psi(ctx, s, re.data(), im.data()), "msm_get_psi");
+        writers.submit<T>(dir + name, std::move(re), std::move(im), shape);
+        if (toml.output_potential) {
+            std::snprintf(name, sizeof name, "/potential_%05d", k);
+            std::vector<T> phi(n_cells), zero(n_cells, (T)0);
+            check(ctx, msm_potential(ctx, s, 1), "msm_potential");
+            check(ctx, msm_get_potential(ctx, s, phi.data()), "msm_get_potential");
+            writers.submit<T>(dir + name, std::move(phi), std::move(zero), shape);
+        }
+    };
+    for (int s = 0; s < ns; ++s) dump(s, 0);   // main.rs:61
+
+    // ---- expanding-box host state (simulation_object.rs:726-760, :939-990)
+    std::vector<ScaleFactorSolver> solvers;
+    std::map<double, double> tau_cache;
+    auto tau_of = [&](double t) {
+        auto it = tau_cache.find(t);
+        if (it == tau_cache.end()) it = tau_cache.emplace(t, get_tau(t, *toml.cosmology)).first;
+        return it->second;
+    };
+    std::vector<T> time(ns, (T)cfg.time), tau(ns, (T)0);
+    if (args.expanding) {
+        solvers.assign(ns, ScaleFactorSolver(*toml.cosmology));
+        for (int s = 0; s < ns; ++s) tau[s] = (T)tau_of((double)time[s]);
+    }
+
+    std::vector<msm_stream_status> st(ns), prev(ns);
+    check(ctx, msm_get_status(ctx, prev.data(), ns), "msm_get_status");
+    const auto t_loop = std::chrono::steady_clock::now();
+    const T tf = (T)toml.final_sim_time, nd = (T)toml.num_data_dumps;
+    for (;;) {
+        bool any_active = false;
+        for (int s = 0; s < ns; ++s) any_active = any_active || prev[s].active;
+        if (!any_active) break;   // main.rs:65: while not_finished()
+        if (!args.expanding) {
+            check(ctx, msm_step(ctx), "msm_step");
+        } else {
+            std::vector<double> a_now(ns), tau_next(ns), kick_a(ns), new_time(ns), new_tau(ns), snapped(ns);
+            for (int s = 0; s < ns; ++s) {
+                a_now[s] = solvers[s].get_a();
+                const T ttnd = (T)(prev[s].current_dumps + 1) * tf / nd - time[s];
+                tau_next[s] = (double)((T)tau_of((double)(time[s] + ttnd)) - tau[s]);
+                snapped[s] = (double)(T)tau_of((double)((T)(prev[s].current_dumps + 1) * tf / nd));
+            }
+            check(ctx, msm_step_begin(ctx, a_now.data(), tau_next.data()), "msm_step_begin");
+            check(ctx, msm_get_status(ctx, st.data(), ns), "msm_get_status");
+            for (int s = 0; s < ns; ++s) {
+                if (!prev[s].active) { kick_a[s] = 0; new_time[s] = (double)time[s]; new_tau[s] = (double)tau[s]; continue; }
+                const T dtau = (T)st[s].dt;
+                T a_sum = 0, t_new = time[s], tau_new = tau[s];
+                for (int half = 0; half < 2; ++half) {
+                    a_sum += (T)solvers[s].get_a();
+                    const T dt_myr = (T)calculate_dt_from_dtau(solvers[s], *toml.cosmology, (double)tau_new, (double)t_new, (double)(dtau / (T)2.0));
+                    solvers[s].step((double)dt_myr);
+                    t_new = t_new + dt_myr;
+                    tau_new = tau_new + dtau / (T)2.0;
+                }
+                kick_a[s] = (double)a_sum;
+                new_time[s] = (double)t_new;
+                new_tau[s] = (double)tau_new;
+            }
+            check(ctx, msm_step_end(ctx, kick_a.data(), new_time.data(), new_tau.data(), snapped.data()), "msm_step_end");
+        }
+        check(ctx, msm_get_status(ctx, st.data(), ns), "msm_get_status");
+        for (int s = 0; s < ns; ++s) {
+            if (st[s].n_steps == prev[s].n_steps) continue;   // stream was already finished
+            if (st[s].aliased) {
+                // the reference panics here (simulation_object.rs:607-617)
+                writers.drain(true);
+                std::fprintf(stderr, "thread 'main' panicked at 'simulation aliased Fourier aliasing occurred; p_mass is %g and the "
+                                     "threshold was set at %g with k2_cutoff = %g' (%s)\n",
+                             st[s].alias_mass, toml.alias_threshold, toml.k2_cutoff, streams[s].sim_name.c_str());
+                msm_destroy(ctx);
+                return 101;
+            }
+            time[s] = (T)st[s].time;
+            tau[s] = (T)st[s].tau;
+            if (st[s].dump) {
+                dump(s, st[s].current_dumps);
+                if (args.expanding) std::printf("(%s) z = %g  [%d/%u]\n", streams[s].sim_name.c_str(), 1.0 / solvers[s].get_a() - 1.0, st[s].current_dumps, toml.num_data_dumps);
+                else std::printf("(%s) t = %g  [%d/%u]\n", streams[s].sim_name.c_str(), st[s].time, st[s].current_dumps, toml.num_data_dumps);
+            }
+            if (!st[s].active && args.verbose)
+                std::printf("Finished %s in %lld seconds\n", streams[s].sim_name.c_str(),
+                            (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_loop).count());
+        }
+        prev = st;
+    }
+    writers.drain(true);
+    msm_destroy(ctx);
+    if (multi_stream)
+        std::printf("Finished all streams in %lld seconds\n",
+                    (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count());
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const Args args = parse_args(argc, argv);
+    try {
+        return args.precision == MSM_F64 ? run<double>(args) : run<float>(args);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    }
+}

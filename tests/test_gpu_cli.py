@@ -1,0 +1,148 @@
+"""GPU: the msm-simulator process surface end to end (TOML in, npz in, NPY dumps out) against
+the numpy oracle run on the same configuration.  Tolerance: 1e-11 * max|psi| per dump (fp64)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sp_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "msm_amd", "bin", "msm-simulator")
+
+
+def toml_text(d):
+    out = []
+    for k, v in d.items():
+        if isinstance(v, dict):
+            continue
+        out.append(f"{k} = " + (f'"{v}"' if isinstance(v, str) else str(v).lower() if isinstance(v, bool) else repr(v)))
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.append(f"\n[{k}]")
+            for kk, vv in v.items():
+                out.append(f"{kk} = " + (f'"{vv}"' if isinstance(vv, str) else repr(vv)))
+    return "\n".join(out) + "\n"
+
+
+def run_cli(tmp_path, cfg, *flags, expect=0):
+    path = tmp_path / "run.toml"
+    path.write_text(toml_text(cfg))
+    r = subprocess.run([BIN, "--toml", str(path), *flags], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == expect, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return r
+
+
+def load_dump(tmp_path, name, k, what="psi"):
+    base = tmp_path / "sim-data" / name / f"{what}_{k:05d}"
+    with open(str(base) + "_real", "rb") as f:
+        re = np.load(f)
+    with open(str(base) + "_imag", "rb") as f:
+        im = np.load(f)
+    assert re.ndim == 4 and re.shape[3] == 1 and re.dtype == np.float64
+    return re[..., 0] + 1j * im[..., 0]
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+def oracle_runs(cfg, expanding=False):
+    sims = []
+    for params in o.simulation_iter(cfg, expanding=expanding):
+        sim = o.SimulationObject(params)
+        sim.dump()                       # main.rs:61, dump 0
+        while sim.not_finished():
+            sim.update()
+        sims.append(sim)
+    return sims
+
+
+TOPHAT = dict(axis_length=30.0, final_sim_time=1.0, cfl=0.5, num_data_dumps=5, total_mass=1e11, ntot=1e6,
+              hbar_=0.05, sim_name="spherical-tophat", k2_cutoff=0.95, alias_threshold=0.02, dims=3, size=16,
+              ics=dict(type="SphericalTophat", radius=5.0, slope=50.0, delta=100.0),
+              sampling=dict(seeds="1 to 2", scheme="Husimi"))
+
+
+def test_static_tophat_streams_and_mft(tmp_path):
+    # examples/spherical-tophat.toml with a short run: 2 Husimi streams + the mean-field run
+    r = run_cli(tmp_path, TOPHAT, "--verbose")
+    assert "Working on simulation spherical-tophat-stream00001" in r.stdout and "Finished all streams" in r.stdout
+    sims = oracle_runs(TOPHAT)
+    assert [s.parameters.sim_name for s in sims] == ["spherical-tophat-stream00001", "spherical-tophat-stream00002",
+                                                      "spherical-tophat"]
+    for sim in sims:
+        assert len(sim.dumps) == 6
+        for k, psi in sim.dumps:
+            assert rel(load_dump(tmp_path, sim.parameters.sim_name, k), psi) < 1e-11, (sim.parameters.sim_name, k)
+    assert not (tmp_path / "sim-data" / "spherical-tophat" / "psi_00006_real").exists()
+
+
+def test_user_specified_wigner_and_potential(tmp_path, golden_dir):
+    # tomls/planeWave3d_e10_sym.toml: npz initial conditions, Wigner streams, unknown keys, output_potential
+    cfg = dict(axis_length=60.0, final_sim_time=5e-6, cfl=0.1, num_data_dumps=2, total_mass=3e16, hbar_=0.01,
+               sim_name="planeWave3d_e10_sym", ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001, dims=3, size=16,
+               output_potential=True,
+               ics=dict(type="UserSpecified", path=os.path.join(golden_dir, "planeWave3d_e10_sym.npz")),
+               cosmology=dict(omega_matter_now=1.0, omega_radiation_now=0.0, h=1e-07, z0=99.0, max_dloga=0.01),
+               sampling=dict(num_streams=16, seeds="3, 7", scheme="Wigner"),
+               remote_storage_parameters=dict(keypair="dev.json", storage_account="streams"))
+    run_cli(tmp_path, cfg)
+    sims = oracle_runs(cfg)
+    assert [s.parameters.sim_name for s in sims][:2] == ["planeWave3d_e10_sym-stream00003", "planeWave3d_e10_sym-stream00007"]
+    for sim in sims:
+        assert len(sim.dumps) == 3 and sim.parameters.n_steps >= 5
+        for k, psi in sim.dumps:
+            assert rel(load_dump(tmp_path, sim.parameters.sim_name, k), psi) < 1e-11
+        # potential_{k} = calculate_potential of the dumped psi, imaginary plane zero (simulation_object.rs:1167-1179)
+        k, psi = sim.dumps[-1]
+        phi = load_dump(tmp_path, sim.parameters.sim_name, k, "potential")
+        sim.psi = psi
+        assert rel(phi.real, sim.calculate_potential()) < 1e-11 and not phi.imag.any()
+
+
+def test_expanding_box(tmp_path):
+    # examples/spherical-tophat-cosmo.toml under the reference's feature "expanding" (test.sh:6)
+    cfg = dict(TOPHAT, sim_name="spherical-tophat-cosmo", final_sim_time=0.6, num_data_dumps=3,
+               sampling=dict(seeds="1 to 1", scheme="Husimi"),
+               cosmology=dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01))
+    r = run_cli(tmp_path, cfg, "--expanding")
+    assert "z = " in r.stdout
+    sims = oracle_runs(cfg, expanding=True)
+    for sim in sims:
+        assert len(sim.dumps) == 4
+        for k, psi in sim.dumps:
+            assert rel(load_dump(tmp_path, sim.parameters.sim_name, k), psi) < 1e-11, (sim.parameters.sim_name, k)
+
+
+def test_test_flag_and_errors(tmp_path, golden_dir):
+    run_cli(tmp_path, TOPHAT, "--test")
+    assert not (tmp_path / "sim-data").exists()          # main.rs:59: ICs only, no dump, no evolution
+    bad = dict(TOPHAT, ics=dict(type="UserSpecified", path=str(tmp_path / "missing.npz")))
+    r = run_cli(tmp_path, bad, expect=1)
+    assert "ics file does not exist" in r.stderr
+    r = run_cli(tmp_path, dict(TOPHAT, size=32, ics=dict(type="UserSpecified",
+                path=os.path.join(golden_dir, "planeWave3d_e10_sym.npz"))), expect=1)
+    assert "Grid size of user-provided data (16) does not match the size specified in the toml (32)" in r.stderr
+    r = run_cli(tmp_path, TOPHAT, "--expanding", expect=1)
+    assert "cosmology" in r.stderr
+    r = subprocess.run([BIN], capture_output=True, text=True)
+    assert r.returncode == 2 and "--toml" in r.stderr
+
+
+def test_aliasing_aborts_like_the_reference(tmp_path):
+    # a Nyquist-corner wavefunction trips check_alias on the first step; the reference panics
+    # (simulation_object.rs:607-617), the CLI exits with Rust's panic status and the same message
+    N = 8
+    idx = np.indices((N, N, N)).sum(axis=0)
+    psi = o.normalize(((-1.0) ** idx).astype(np.complex128), 30.0 / N, 3)
+    np.savez(tmp_path / "nyq.npz", real=psi.real, imag=psi.imag)
+    cfg = dict(TOPHAT, size=N, ics=dict(type="UserSpecified", path=str(tmp_path / "nyq.npz")))
+    del cfg["sampling"]
+    r = run_cli(tmp_path, cfg, expect=101)
+    assert "simulation aliased" in r.stderr and "k2_cutoff = 0.95" in r.stderr
+    assert (tmp_path / "sim-data" / "spherical-tophat" / "psi_00000_real").exists()
+    assert not (tmp_path / "sim-data" / "spherical-tophat" / "psi_00001_real").exists()
