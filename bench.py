@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 import msm_amd  # noqa: E402
 from msm_amd.ics import plane_wave_psi  # noqa: E402
+from msm_amd.sharding import allreduce_density, partition_streams  # noqa: E402
 
 PLANE = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=64, total_mass=3e16,
              hbar_=0.01, ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)
@@ -90,8 +91,9 @@ def main():
 
     dist = torch = None
     hip_stream = None
-    if world > 1:
-        import torch
+    use_dist = world > 1 or os.environ.get("MSM_BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on one GPU
+    if use_dist:
+        import torch            # before the first Evolver: libmsm_hip.so then binds to the HIP runtime torch loaded
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -99,8 +101,7 @@ def main():
 
     # block partition of the seed list 1..streams (simulator/src/utils/io.rs:183-213 order)
     per = (args.streams + world - 1) // world
-    first = rank * per
-    n_local = max(0, min(per, args.streams - first))
+    first, n_local = partition_streams(args.streams, world, rank)
     seeds = [first + 1 + i for i in range(n_local)]
 
     ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank,
@@ -114,24 +115,24 @@ def main():
     del psi0
 
     dens = work = None
-    if world > 1:
+    if use_dist:
         dens = [torch.empty(n3, dtype=torch.float64, device="cuda") for _ in range(2)]
         work = [None, None]
 
     def one_step(i):
-        if world > 1:
+        if use_dist:
             b = i & 1
             if work[b] is not None:
                 work[b].wait()
             ev.step_density(dens[b].data_ptr())                 # the step leaves sum_s |psi_s|^2 here
         ev.update()
-        if world > 1:
-            work[b] = dist.all_reduce(dens[b], async_op=True)   # sum over ranks; mean = / streams
+        if use_dist:
+            work[b] = allreduce_density(dist, dens[b], async_op=True)   # sum over ranks; mean = / streams
         ev.sync()                                               # per-step status (dt, dump flags) on the host
 
     def barrier():
         ev.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -143,7 +144,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
-    if world > 1:
+    if use_dist:
         for w in work:
             if w is not None:
                 w.wait()
@@ -156,7 +157,7 @@ def main():
     steps_done = min(s.n_steps for s in st) - args.warmup if n_local else args.steps
     aliased = sum(s.aliased for s in st)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,7 +189,7 @@ def main():
             "config": {"workload": f"{N}^3 fp64 x {args.streams} streams, plane-wave ICs + Wigner noise "
                                    f"(tomls/planeWave3d_e10_sym.toml, size override), static box",
                        "streams_per_gpu": per, "batch_streams": args.batch,
-                       "density_allreduce": world > 1, "event_ms_per_step": ev_ms / args.steps},
+                       "density_allreduce": use_dist, "event_ms_per_step": ev_ms / args.steps},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:
@@ -196,7 +197,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ev.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -483,55 +483,53 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a,
     using G = Geom<N, 0>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
-    // one workgroup per (tile, stream); the two streams of a pair sit in neighbouring workgroups so
-    // that the second read of the pair's W tile is served on-chip
-    const int ls = 2 * blockIdx.y + (blockIdx.x & 1);
-    if (ls >= a.nb) return;
-    const int sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    const int h = ls & 1, p = ls >> 1;
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool act_a = a.active[sa] != 0;
+    const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+    if (!act_a && !act_b) return;
 
-    const Tile<N, 0> t(blockIdx.x >> 1, threadIdx.x);
+    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
     cplx* tw = lds + G::LPW * G::LINE_LDS;
     load_twiddles<N, 0>(tw, a.tw);
     cplx* line = lds + t.ln * G::LINE_LDS;
-    const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-    cplx* __restrict__ x = a.Xout + (size_t)ls * a.n3;
-    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-    const real kc = kick[sg];
 
-    real phi[E];
+    real phi[2][E];
     {
+        const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
         cplx vw[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
         LineFft<real, N, +1>::run(vw, t.j0, line, tw);
 #pragma unroll
+        for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool act = h == 0 ? act_a : act_b;
+        if (!act) continue;   // uniform over the workgroup
+        const int sg = h == 0 ? sa : sb;
+        cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
+        const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+        const real kc = kick[sg];
+        if constexpr (G::USES_LDS) __syncthreads();   // also keeps the psi loads below the previous transform
+        cplx v[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+        LineFft<real, N, +1>::run(v, t.j0, line, tw);
+#pragma unroll
         for (int q = 0; q < E; ++q) {
-            // select on VALUES: a select between two elements of the register array would turn into a
-            // runtime-indexed access and push the whole array to scratch memory
-            real re = vw[q].x, im = vw[q].y;
-            asm volatile("" : "+v"(re), "+v"(im));
-            phi[q] = h == 0 ? re : im;
+            real sn, cs;
+            sincos_t(kc * phi[h][q], &sn, &cs);
+            v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
         }
+        if constexpr (G::USES_LDS) __syncthreads();
+        LineFft<real, N, -1>::run(v, t.j0, line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
     }
-    if constexpr (G::USES_LDS) __syncthreads();   // also keeps the psi loads below the phi transform
-    cplx v[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
-#pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-    LineFft<real, N, +1>::run(v, t.j0, line, tw);
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        real sn, cs;
-        sincos_t(kc * phi[q], &sn, &cs);
-        v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
-    }
-    if constexpr (G::USES_LDS) __syncthreads();
-    LineFft<real, N, -1>::run(v, t.j0, line, tw);
-#pragma unroll
-    for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
 }
 
 // z pass, fused: forward FFT, Green's multiply -C / k^2 with the k = 0 mode
@@ -1242,7 +1240,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         timed(PK_FWD_X, [&] {
-            k_kick_fwdx<N><<<dim3((unsigned)(2 * (n3_ / N / G0::LPW)), (unsigned)((nb + 1) / 2)), dim3(G0::THREADS), 0, stream_>>>(p, st_.kick);
+            k_kick_fwdx<N><<<dim3((unsigned)(n3_ / N / G0::LPW), (unsigned)((nb + 1) / 2)), dim3(G0::THREADS), 0, stream_>>>(p, st_.kick);
         });
     });
     launch_psi<-1, 0, 1>(1, a, nb, PK_FWD_Y);

@@ -330,3 +330,48 @@ def test_full_size_properties_256():
         assert abs(np.sum(np.abs(a) ** 2) * d["dx"] ** 3 - 1) < 1e-12
         st = ev.status()
         assert st[0].dt == st[1].dt and st[0].dt <= d["kinetic_dt"]
+
+
+_DENSITY_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                      # first: libmsm_hip.so must bind to the HIP runtime torch already loaded
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import sp_oracle as o
+from msm_amd import Evolver
+TOPHAT = dict(axis_length=30.0, final_sim_time=40.0, cfl=0.5, num_data_dumps=200, total_mass=1e11,
+              hbar_=0.05, k2_cutoff=0.95, alias_threshold=0.02)
+N, ns = 16, 5
+toml = dict(TOPHAT, sim_name="t", dims=3, size=N, ics=dict(type="SphericalTophat", radius=5.0, slope=50.0, delta=100.0))
+base = o.SimulationObject(list(o.simulation_iter(toml))[-1]).psi
+dens = torch.zeros(N ** 3, dtype=torch.float64, device="cuda")
+dens2 = torch.zeros(N ** 3, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+with Evolver(size=N, n_streams=ns, batch_streams=2, hip_stream=torch.cuda.current_stream().cuda_stream or None, **TOPHAT) as ev:
+    for s in range(ns):
+        ev.set_psi(s, o.sample_quantum_perturbation(base, 30.0 / N, 3, 1e11, 1e3, "Husimi", seed=s + 1))
+    ev.density_sum(dens2.data_ptr()); ev.sync(); torch.cuda.synchronize()
+    want0 = sum(np.abs(ev.get_psi(s)) ** 2 for s in range(ns)).reshape(-1)
+    assert np.allclose(dens2.cpu().numpy(), want0, rtol=1e-13, atol=0)
+    ev.step_density(dens.data_ptr())
+    for _ in range(2):
+        ev.update()
+    ev.sync(); torch.cuda.synchronize()
+    want = sum(np.abs(ev.get_psi(s)) ** 2 for s in range(ns)).reshape(-1)
+    assert np.allclose(dens.cpu().numpy(), want, rtol=1e-12, atol=0), np.abs(dens.cpu().numpy() - want).max()
+    ev.step_density(None)
+    ev.density_sum(dens2.data_ptr()); ev.sync(); torch.cuda.synchronize()
+    assert np.allclose(dens2.cpu().numpy(), want, rtol=1e-12, atol=0)
+print("density ok")
+"""
+
+
+def test_step_density_product():
+    # msm_step_density: sum_s |psi_s(t + dt)|^2 left by the step in a caller-owned device buffer (a torch
+    # tensor, as bench.py uses it before the RCCL all-reduce), and msm_density_sum computed on demand, both
+    # against the downloaded wavefunctions.  Own process: torch has to be imported before the library is loaded.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DENSITY_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "density ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
