@@ -623,13 +623,13 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
 // MODE 0: sum -> alias_sum;  MODE 1: max (NaN wins) -> maxphi bits.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce_partials(State st, const double* __restrict__ partial, int ntiles,
-                                                         int s0, const int* __restrict__ active) {
+                                                         int nvalid, int s0, const int* __restrict__ active) {
     __shared__ double red[256];
     const int s = s0 + blockIdx.x;
     if (!active[s]) return;
     const double* __restrict__ p = partial + (size_t)s * ntiles;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < ntiles; i += 256) {
+    for (int i = threadIdx.x; i < nvalid; i += 256) {   // nvalid <= ntiles: tiles the producing pass really has
         const double v = p[i];
         if (MODE == 0) acc += v;
         else acc = (v != v) ? v : ((acc != acc) ? acc : (v > acc ? v : acc));
@@ -899,7 +899,7 @@ class Engine final : public IEngine {
     }
 
     msm_config cfg_;
-    int N_ = 0, ns_ = 0, batch_ = 0, dims_ = 3, ntiles_ = 0;
+    int N_ = 0, ns_ = 0, batch_ = 0, dims_ = 3, ntiles_ = 0, tiles_x_ = 0, tiles_z_ = 0;
     size_t n3_ = 0;
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
@@ -1035,7 +1035,9 @@ int Engine::init(std::string& err) {
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
-        ntiles_ = (int)std::max(n3_ / N / Geom<N, 0>::LPW, n3_ / N / Geom<N, 2>::LPW);
+        tiles_x_ = (int)(n3_ / N / Geom<N, 0>::LPW);
+        tiles_z_ = (int)(n3_ / N / Geom<N, 2>::LPW);
+        ntiles_ = std::max(tiles_x_, tiles_z_);
     });
 
     // ---- device memory
@@ -1184,7 +1186,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
             else k_phi_out<N, 0, 1><<<grid0, block0, 0, stream_>>>(p);
         });
     });
-    if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0, act);
+    if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tiles_x_, s0, act);
     if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
@@ -1255,7 +1257,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
             k_fwdz_invz<N><<<dim3((unsigned)(n3_ / N / GS::LPW), (unsigned)nb), dim3(GS::THREADS), 0, stream_>>>(f);
         });
     });
-    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, s0, st_.active);
+    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tiles_z_, s0, st_.active);
     k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
     // streams that are still running: finish psi(t + dt) only as far as the next step needs it,
     // i.e. its density (and the ensemble density if asked for); psi itself is not written back
