@@ -137,6 +137,35 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     return red[0];
 }
 
+// 1/x for the Green's function: hardware reciprocal plus one Newton step (about 1 ulp in double),
+// a third of the instructions of the IEEE division expansion.
+__device__ __forceinline__ double recip_t(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ float recip_t(float x) { return 1.0f / x; }
+
+// max of two values per thread over the workgroup in one pass: wavefront shuffles, then one LDS
+// round over the (at most 16) wavefronts.  NaN wins so that a poisoned potential stays visible.
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+template <int THREADS>
+__device__ __forceinline__ void block_max2(double& a, double& b, double* red) {
+    constexpr int WAVES = (THREADS + 63) / 64;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a = nanmax(a, __shfl_xor(a, off));
+        b = nanmax(b, __shfl_xor(b, off));
+    }
+    if constexpr (WAVES > 1) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+        __syncthreads();
+        a = red[0]; b = red[1];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) { a = nanmax(a, red[2 * w]); b = nanmax(b, red[2 * w + 1]); }
+    }
+}
+
 // Tile geometry shared by all pass kernels.  AX = 0: lines along x (unit
 // stride); 1: along y (stride N); 2: along z (stride N^2).  c1/c2 are the two
 // coordinates that are constant along the line, in (x,y,z) order with the pass
@@ -559,7 +588,7 @@ __global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_poisson_mid(PoisArgs 
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const real k2 = (kxy + a.ksq[t.j0 + TPL * q]) * a.fourpi2;
-        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c / k2) * a.inv_n3;
+        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
         v[q] = cscale(v[q], g);
     }
     if constexpr (G::USES_LDS) __syncthreads();  // all exchange reads of the forward run are done
@@ -575,7 +604,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
     using G = Geom<N, 0>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
-    __shared__ double red[TRACKMAX ? G::THREADS : 1];
+    __shared__ double red[TRACKMAX ? 32 : 1];
     const int p = blockIdx.y;
     const int sa = a.s0 + 2 * p, sb = sa + 1;
     const bool has_b = (2 * p + 1 < a.nb);
@@ -609,12 +638,10 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
         }
     }
     if constexpr (TRACKMAX) {
-        const double ra = block_max<G::THREADS>(ma, red);
-        __syncthreads();
-        const double rb = block_max<G::THREADS>(mb, red);
+        block_max2<G::THREADS>(ma, mb, red);
         if (threadIdx.x == 0) {
-            a.partial[(size_t)sa * a.ntiles + blockIdx.x] = ra;
-            if (has_b) a.partial[(size_t)sb * a.ntiles + blockIdx.x] = rb;
+            a.partial[(size_t)sa * a.ntiles + blockIdx.x] = ma;
+            if (has_b) a.partial[(size_t)sb * a.ntiles + blockIdx.x] = mb;
         }
     }
 }
