@@ -16,6 +16,7 @@
 // Between steps only psi_k is kept; psi is rebuilt on demand for downloads.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -646,6 +647,337 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Two-pass Poisson solve for N = 256 (y split as 16 x 16):
+//   pass A  (x lines and the outer radix-16 stage of y) lives inside the x-pass kernels of psi,
+//   pass B  (inner radix-16 stage of y, all of z, Green's multiply, and back) is one kernel,
+// so the pair-packed work array crosses HBM twice per solve instead of four times.
+// With y = b + 16 t, ky = t' + 16 b':  F_y = DFT16_b[ w^(b t') DFT16_t[.] ],  w = e^(-2 pi i / 256).
+// An A tile is 32 x-lines: 16 rows y = b + 16 t of the two planes z = 2 zh + zl.  Between the passes
+// W is stored as  T[t'][kx >> 2][b][zh][kx bit 1][zl][kx bit 0] : 128-byte blocks for the A tiles,
+// one contiguous 256-KiB run per (t', kx >> 2) for pass B, whose two 512-thread workgroups (kx bit 1
+// = 0 / 1) take alternate 64-byte chunks of the run and are placed 8 blocks apart so that they
+// share an L2.
+// ---------------------------------------------------------------------------
+namespace tp {
+constexpr int N = 256;
+constexpr int A_THREADS = 512, A_LINE = Geom<N, 0>::LINE_LDS;
+constexpr int A_HALF = 16 * A_LINE + 8;            // zl = 1 lines start 128 B off the bank period of zl = 0
+constexpr int A_LDS = 2 * A_HALF + N;              // + twiddle table
+constexpr int A_TILES = 2048;                      // zh (128) x b (16)
+constexpr size_t T_TP = (size_t)64 * 16384;        // stride of t' in T
+constexpr int B_THREADS = 512, B_LINE = 272;       // reals per padded z line; 272 = 16 mod 32 keeps line pairs on disjoint banks
+constexpr int B_BLOCKS = 2 * 1024;                 // two half-runs per (t', kx >> 2)
+}
+
+struct TileA {
+    int j0, zl, t, b, zh;
+    size_t base;     // first element of this thread's x line in the natural layout
+    cplx* line;      // its padded LDS line
+    __device__ __forceinline__ TileA(int tile, int tid, cplx* lds) {
+        j0 = tid & 15;
+        const int ln = tid >> 4;
+        zl = ln >> 4; t = ln & 15;
+        zh = tile >> 4; b = tile & 15;
+        base = ((size_t)(2 * zh + zl) * tp::N + (b + 16 * t)) * tp::N;
+        line = lds + zl * tp::A_HALF + t * tp::A_LINE;
+    }
+};
+
+// Line role (thread = 16 kx of one line) -> column role (thread = one (kx, zl), the 16 lines t),
+// radix-16 stage over t, store to T.  Barriers inside; all 512 threads call.
+__device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* lds, cplx* __restrict__ wT) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.line[lds_pad(t.j0 + 16 * q)] = v[q];
+    __syncthreads();
+    const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
+    const cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = col[q * tp::A_LINE];
+    dft<16, -1, real>(v);
+    cplx* __restrict__ w = wT + ((size_t)kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[(size_t)q * tp::T_TP] = v[q];
+}
+
+// The way back: load from T, inverse radix-16 stage over t', column role -> line role.
+__device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* lds, const cplx* __restrict__ wT) {
+    const int tid = threadIdx.x;
+    const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
+    const cplx* __restrict__ w = wT + ((size_t)kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = w[(size_t)q * tp::T_TP];
+    dft<16, +1, real>(v);
+    cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) col[q * tp::A_LINE] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = t.line[lds_pad(t.j0 + 16 * q)];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void a_load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
+    if (threadIdx.x < tp::N) tw_lds[threadIdx.x] = tw_g[threadIdx.x];
+}
+
+// k_invx_rho on A tiles: W leaves as T (x and outer-y stage done).
+template <int DRIFT, int DENS>
+__global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho2(PoisArgs a) {
+    constexpr int N = tp::N, E = 16, TPL = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
+
+    double dacc[DENS ? E : 1];
+    if constexpr (DENS) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) dacc[q] = 0.0;
+    }
+    const int pairs = (a.nb + 1) / 2;
+    for (int p = 0; p < pairs; ++p) {
+        const int sa = a.s0 + 2 * p, sb = sa + 1;
+        const bool act_a = a.active[sa] != 0;
+        const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+        if (!act_a && !act_b) continue;   // uniform over the workgroup
+        real rho[2][E];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool act = h == 0 ? act_a : act_b;
+            if (act) {
+                const int sg = h == 0 ? sa : sb;
+                const cplx* __restrict__ x = a.X + (size_t)(2 * p + h) * a.n3;
+                cplx v[E];
+#pragma unroll
+                for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
+                if constexpr (DRIFT) {
+                    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+#pragma unroll
+                    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+                }
+                LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+#pragma unroll
+                for (int q = 0; q < E; ++q) {
+                    v[q] = cscale(v[q], a.scale);
+                    const real m2 = v[q].x * v[q].x + v[q].y * v[q].y;
+                    rho[h][q] = a.mass_factor * m2;
+                    if constexpr (DENS) dacc[q] += (double)m2;
+                }
+                __syncthreads();   // exchange reads done before the next run writes
+            } else {
+#pragma unroll
+                for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
+            }
+        }
+        cplx v[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
+        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        a_store_T(v, t, lds, a.W + (size_t)p * a.n3);
+        __syncthreads();
+    }
+    if constexpr (DENS) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];
+    }
+}
+
+// rho from a stored psi on A tiles (first step, msm_potential).
+__global__ __launch_bounds__(tp::A_THREADS) void k_rho_pass2(PoisArgs a) {
+    constexpr int N = tp::N, E = 16, TPL = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool has_b = (2 * p + 1 < a.nb);
+    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
+    const cplx* __restrict__ xa = a.X + (size_t)(a.x_local ? 2 * p : sa) * a.n3;
+    const cplx* __restrict__ xb = a.X + (size_t)(a.x_local ? 2 * p + 1 : sb) * a.n3;
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const cplx va = xa[t.base + t.j0 + TPL * q];
+        real rb = (real)0;
+        if (has_b) {
+            const cplx vb = xb[t.base + t.j0 + TPL * q];
+            rb = a.mass_factor * (vb.x * vb.x + vb.y * vb.y);
+        }
+        v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), rb);
+    }
+    LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+    a_store_T(v, t, lds, a.W + (size_t)p * a.n3);
+}
+
+// k_kick_fwdx on A tiles: phi_a + i phi_b comes back from T.
+__global__ __launch_bounds__(tp::A_THREADS) void k_kick_fwdx2(PoisArgs a, const real* __restrict__ kick) {
+    constexpr int N = tp::N, E = 16, TPL = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool act_a = a.active[sa] != 0;
+    const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+    if (!act_a && !act_b) return;
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
+
+    real phi[2][E];
+    {
+        cplx vw[E];
+        a_load_T(vw, t, lds, a.W + (size_t)p * a.n3);
+        LineFft<real, N, +1>::run(vw, t.j0, t.line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool act = h == 0 ? act_a : act_b;
+        if (!act) continue;   // uniform over the workgroup
+        const int sg = h == 0 ? sa : sb;
+        cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
+        const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+        const real kc = kick[sg];
+        __syncthreads();   // also keeps the psi loads below the previous transform
+        cplx v[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+        LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            real sn, cs;
+            sincos_t(kc * phi[h][q], &sn, &cs);
+            v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
+        }
+        __syncthreads();
+        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
+    }
+}
+
+// k_phi_out on A tiles.
+template <int STOREPHI, int TRACKMAX>
+__global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
+    constexpr int N = tp::N, E = 16, TPL = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    __shared__ double red[TRACKMAX ? 32 : 1];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool has_b = (2 * p + 1 < a.nb);
+    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
+    cplx v[E];
+    a_load_T(v, t, lds, a.W + (size_t)p * a.n3);
+    LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+
+    real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
+    real* __restrict__ pb = a.PHI + (size_t)(2 * p + 1) * a.n3;
+    double ma = 0.0, mb = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const size_t g = t.base + t.j0 + TPL * q;
+        if constexpr (STOREPHI) {
+            pa[g] = v[q].x;
+            if (has_b) pb[g] = v[q].y;
+        }
+        if constexpr (TRACKMAX) {
+            ma = nanmax(fabs((double)v[q].x), ma);
+            mb = nanmax(fabs((double)v[q].y), mb);
+        }
+    }
+    if constexpr (TRACKMAX) {
+        block_max2<tp::A_THREADS>(ma, mb, red);
+        if (threadIdx.x == 0) {
+            a.partial[(size_t)sa * a.ntiles + blockIdx.x] = ma;
+            if (has_b) a.partial[(size_t)sb * a.ntiles + blockIdx.x] = mb;
+        }
+    }
+}
+
+// Pass B: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
+// simulation_object.rs:1076-1102), and both stages back, on one half-run of T in place.
+__global__ __launch_bounds__(tp::B_THREADS) void k_poisson_b(PoisArgs a) {
+    constexpr int N = tp::N, LINE = tp::B_LINE;
+    __shared__ real plane[32 * LINE];
+    __shared__ cplx tw[N];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
+    if (tid < N) tw[tid] = a.tw[tid];   // first read is behind the exchange barriers
+
+    const int bx = blockIdx.x;
+    const int half = (bx >> 3) & 1, run = ((bx >> 4) << 3) | (bx & 7);   // partner half-run 8 blocks away
+    const int tpi = run >> 6, kxh = run & 63;                            // t', kx >> 2
+    cplx* __restrict__ w = a.W + (size_t)p * a.n3 + (size_t)run * 16384 + half * 4 + (tid >> 2) * 8 + (tid & 3);
+
+    // role b: this thread is (z = tid >> 1, kx bit 0 = tid & 1) and holds the 16 values b (then b')
+    cplx v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = w[q * 1024];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], a.tw[(q * tpi) & (N - 1)]);
+    dft<16, -1, real>(v);
+
+    // role z: this thread is (j0 = tid & 15, line L = tid >> 4 = 2 b' + kx bit 0) and holds z = j0 + 16 q
+    real* colw = plane + (tid & 1) * LINE + lds_pad(tid >> 1);
+    const int j0 = tid & 15, L = tid >> 4;
+    real* line = plane + L * LINE;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) colw[q * 2 * LINE] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = line[lds_pad(j0 + 16 * q)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) colw[q * 2 * LINE] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = line[lds_pad(j0 + 16 * q)];
+    __syncthreads();
+
+    LineFftSplit<real, N, -1>::run(v, j0, line, tw);
+
+    const int kx = (kxh << 2) | (half << 1) | (L & 1), ky = tpi + 16 * (L >> 1);
+    const real kxy = a.ksq[kx] + a.ksq[ky];   // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const real k2 = (kxy + a.ksq[j0 + 16 * q]) * a.fourpi2;
+        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
+        v[q] = cscale(v[q], g);
+    }
+    __syncthreads();
+    LineFftSplit<real, N, +1>::run(v, j0, line, tw);
+    __syncthreads();
+
+#pragma unroll
+    for (int q = 0; q < 16; ++q) line[lds_pad(j0 + 16 * q)] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = colw[q * 2 * LINE];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) line[lds_pad(j0 + 16 * q)] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = colw[q * 2 * LINE];
+
+    dft<16, +1, real>(v);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], a.tw[(q * tpi) & (N - 1)]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q * 1024] = v[q];
+}
+
 // Reduce the per-workgroup partials of one stream in a fixed order (bitwise reproducible).
 // MODE 0: sum -> alias_sum;  MODE 1: max (NaN wins) -> maxphi bits.
 template <int MODE>
@@ -945,6 +1277,7 @@ class Engine final : public IEngine {
     msm_stream_status* h_status_ = nullptr;
     std::vector<int> host_active_;
     bool fourier_ = false;   // P_ holds psi_k (after the first step)
+    bool two_pass_ = false;  // Poisson solve in two passes over the work array (N = 256, double)
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
@@ -1059,6 +1392,8 @@ int Engine::init(std::string& err) {
     c_.inv_n3 = (real)(1.0 / ((double)N_ * N_ * N_));
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
+    two_pass_ = (N_ == tp::N) && sizeof(real) == 8;
+    if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
@@ -1192,10 +1527,25 @@ PoisArgs Engine::pois_args(int s0, int nb, const int* act) const {
 }
 
 // y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
+// (two-pass layout: W holds T and one pass-B kernel replaces the three middle passes)
 void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x, const int* act) {
     if (!act) act = st_.active;
     const int pairs = (nb + 1) / 2;
     const PoisArgs p = pois_args(s0, nb, act);
+    if (two_pass_) {
+        if constexpr (sizeof(real) == 8) {
+            timed(PK_POISSON_Z, [&] { k_poisson_b<<<dim3(tp::B_BLOCKS, (unsigned)pairs), dim3(tp::B_THREADS), 0, stream_>>>(p); });
+            const dim3 grid(tp::A_TILES, (unsigned)pairs), block(tp::A_THREADS);
+            if (with_x) timed(PK_PHI_X, [&] {
+                if (store_phi && track_max) k_phi_out2<1, 1><<<grid, block, 0, stream_>>>(p);
+                else if (store_phi) k_phi_out2<1, 0><<<grid, block, 0, stream_>>>(p);
+                else k_phi_out2<0, 1><<<grid, block, 0, stream_>>>(p);
+            });
+        }
+        if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::A_TILES, s0, act);
+        if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
+        return;
+    }
     PsiArgs a{};
     a.src = W_; a.dst = W_; a.n3 = n3_; a.active = act; a.s0 = s0; a.pair_nb = nb; a.tw = tw_; a.scale = (real)1;
     dispatch_n(N_, [&](auto nc) {
@@ -1221,7 +1571,10 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
 void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act) {
     PoisArgs p = pois_args(s0, nb, act);
     p.X = X; p.x_local = local ? 1 : 0;
-    dispatch_n(N_, [&](auto nc) {
+    if (two_pass_) {
+        if constexpr (sizeof(real) == 8)
+            timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+    } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         const dim3 grid0((unsigned)(n3_ / N / G0::LPW), (unsigned)((nb + 1) / 2));
@@ -1255,7 +1608,10 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     launch_psi<+1, 1, 0>(2, a, nb, PK_INV_Z);
     a.src = X_; a.src_local = 1;
     launch_psi<+1, 1, 0>(1, a, nb, PK_INV_Y);
-    dispatch_n(N_, [&](auto nc) {
+    if (two_pass_) {
+        if constexpr (sizeof(real) == 8)
+            timed(PK_INVX_RHO, [&] { k_invx_rho2<1, 0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+    } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         timed(PK_INVX_RHO, [&] {
@@ -1265,7 +1621,12 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     // phi at the half-drifted psi, left as F_x[phi_a + i phi_b] in W
     poisson_tail(s0, nb, false, false, false);
     // psi_k = D F[ kick psi ], then on into psi = F^-1[ psi_k ]
-    dispatch_n(N_, [&](auto nc) {
+    if (two_pass_) {
+        if constexpr (sizeof(real) == 8)
+            timed(PK_FWD_X, [&] {
+                k_kick_fwdx2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p, st_.kick);
+            });
+    } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         timed(PK_FWD_X, [&] {
@@ -1290,7 +1651,13 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     // i.e. its density (and the ensemble density if asked for); psi itself is not written back
     launch_psi<+1, 0, 0>(1, a, nb, PK_INV_Y);
     p.dens = step_dens_;
-    dispatch_n(N_, [&](auto nc) {
+    if (two_pass_) {
+        if constexpr (sizeof(real) == 8)
+            timed(PK_INVX_RHO, [&] {
+                if (step_dens_) k_invx_rho2<0, 1><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
+                else k_invx_rho2<0, 0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
+            });
+    } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         const dim3 grid((unsigned)(n3_ / N / G0::LPW)), block(G0::THREADS);

@@ -163,4 +163,64 @@ struct LineFft {
     }
 };
 
+// The same transform for workgroups whose LDS budget holds only one REAL plane of the tile:
+// every exchange moves the real parts and then the imaginary parts through `line`
+// (LINE padded reals per line).  On return other threads may still be reading `line`.
+template <typename T, int N, int SGN>
+struct LineFftSplit {
+    using P = Plan<N>;
+    static constexpr int E = P::E, TPL = N / E;
+
+    template <int SIDX, int NS>
+    static __device__ __forceinline__ void stage(cx<T> (&v)[E], int j0, T* line, const cx<T>* tw) {
+        constexpr int R = SIDX == 0 ? P::R0 : (SIDX == 1 ? P::R1 : P::R2);
+        constexpr int BPT = E / R;
+        constexpr bool LAST = (SIDX == P::S - 1);
+        int o[BPT];
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const int b = j0 + TPL * u;
+            const int k = b & (NS - 1);
+            cx<T> a[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) a[t] = v[u + t * BPT];
+            if constexpr (NS > 1) {
+                constexpr int TWS = N / (NS * R);
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    const cx<T> w = tw[k * t * TWS];
+                    a[t] = (SGN < 0) ? cmul(a[t], w) : cmulc(a[t], w);
+                }
+            }
+            dft<R, SGN, T>(a);
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[u + t * BPT] = a[t];
+            o[u] = (b - k) * R + k;
+        }
+        if constexpr (!LAST) {
+#pragma unroll
+            for (int u = 0; u < BPT; ++u)
+#pragma unroll
+                for (int t = 0; t < R; ++t) line[lds_pad(o[u] + t * NS)] = v[u + t * BPT].x;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q].x = line[lds_pad(j0 + TPL * q)];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < BPT; ++u)
+#pragma unroll
+                for (int t = 0; t < R; ++t) line[lds_pad(o[u] + t * NS)] = v[u + t * BPT].y;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q].y = line[lds_pad(j0 + TPL * q)];
+            if constexpr (SIDX + 2 < P::S) __syncthreads();
+            stage<SIDX + 1, NS * R>(v, j0, line, tw);
+        }
+    }
+
+    static __device__ __forceinline__ void run(cx<T> (&v)[E], int j0, T* line, const cx<T>* tw) {
+        stage<0, 1>(v, j0, line, tw);
+    }
+};
+
 }  // namespace msm

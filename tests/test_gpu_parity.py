@@ -332,6 +332,44 @@ def test_full_size_properties_256():
         assert st[0].dt == st[1].dt and st[0].dt <= d["kinetic_dt"]
 
 
+def test_steps_and_potential_256_vs_cpu_port():
+    """256^3 (the size the two-pass Poisson path serves): three streams -- one pair and one
+    unpaired -- against the C restatement of the reference step (oracle/sp_cpu.c)."""
+    import sp_cpu
+    N, base = 256, dict(TOPHAT, cfl=0.05)
+    psis = [o.normalize(rand_psi(N, 10 + s) * 0.05 + 1.0, 30.0 / N, 3) for s in range(3)]
+    sims = []
+    for s in range(3):
+        sim = sp_cpu.CpuSim(N, **base)
+        sim.set_psi(psis[s])
+        sims.append(sim)
+    with Evolver(size=N, n_streams=3, **base) as ev:
+        for s in range(3):
+            ev.set_psi(s, psis[s])
+        ev.calculate_potential(0, 3)
+        for s in range(3):
+            pm = sims[s].potential()
+            assert rel_err(ev.get_potential(s), sims[s].get_phi()) < 1e-12
+            assert abs(ev.status()[s].max_phi / pm - 1) < 1e-12
+        for i in range(2):
+            ev.update()
+            infos = [sim.update() for sim in sims]
+            st = ev.status()
+            for s in range(3):
+                assert abs(st[s].dt / infos[s]["dt"] - 1) < 1e-12
+                assert abs(st[s].max_phi / infos[s]["max_phi"] - 1) < 1e-11
+                assert abs(st[s].time / infos[s]["time"] - 1) < 1e-12
+        for s in range(3):
+            assert rel_err(ev.get_psi(s), sims[s].get_psi()) < 1e-11
+            assert rel_err(ev.get_psik(s), sims[s].get_psik()) < 1e-11
+        ev.calculate_potential(0, 3)
+        for s in range(3):
+            sims[s].potential()
+            assert rel_err(ev.get_potential(s), sims[s].get_phi()) < 1e-11
+    for sim in sims:
+        sim.close()
+
+
 _DENSITY_SCRIPT = r"""
 import sys
 import numpy as np
