@@ -146,6 +146,10 @@ __device__ __forceinline__ double recip_t(double x) {
 }
 __device__ __forceinline__ float recip_t(float x) { return 1.0f / x; }
 
+// Hides a lane offset from common-subexpression elimination: addresses formed from the result are
+// rebuilt where they are used instead of being kept (or spilled) since their first use.
+__device__ __forceinline__ unsigned fresh(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
 // max of two values per thread over the workgroup in one pass: wavefront shuffles, then one LDS
 // round over the (at most 16) wavefronts.  NaN wins so that a poisoned potential stays visible.
 __device__ __forceinline__ double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
@@ -686,7 +690,7 @@ struct TileA {
 
 // Line role (thread = 16 kx of one line) -> column role (thread = one (kx, zl), the 16 lines t),
 // radix-16 stage over t, store to T.  Barriers inside; all 512 threads call.
-__device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* lds, cplx* __restrict__ wT) {
+__device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* lds, cplx* __restrict__ wT, size_t grid_off) {
     const int tid = threadIdx.x;
     __syncthreads();
 #pragma unroll
@@ -697,18 +701,18 @@ __device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* l
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = col[q * tp::A_LINE];
     dft<16, -1, real>(v);
-    cplx* __restrict__ w = wT + ((size_t)kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7);
+    const unsigned off = (unsigned)((kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) w[(size_t)q * tp::T_TP] = v[q];
+    for (int q = 0; q < 16; ++q) (wT + (grid_off + (size_t)q * tp::T_TP))[off] = v[q];
 }
 
 // The way back: load from T, inverse radix-16 stage over t', column role -> line role.
-__device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* lds, const cplx* __restrict__ wT) {
+__device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* lds, const cplx* __restrict__ wT, size_t grid_off) {
     const int tid = threadIdx.x;
     const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
-    const cplx* __restrict__ w = wT + ((size_t)kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7);
+    const unsigned off = (unsigned)((kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = w[(size_t)q * tp::T_TP];
+    for (int q = 0; q < 16; ++q) v[q] = (wT + (grid_off + (size_t)q * tp::T_TP))[off];
     dft<16, +1, real>(v);
     cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
 #pragma unroll
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho2(PoisArgs a) {
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
         LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
-        a_store_T(v, t, lds, a.W + (size_t)p * a.n3);
+        a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
         __syncthreads();
     }
     if constexpr (DENS) {
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_rho_pass2(PoisArgs a) {
         v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), rb);
     }
     LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
-    a_store_T(v, t, lds, a.W + (size_t)p * a.n3);
+    a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
 }
 
 // k_kick_fwdx on A tiles: phi_a + i phi_b comes back from T.
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_kick_fwdx2(PoisArgs a, const 
     real phi[2][E];
     {
         cplx vw[E];
-        a_load_T(vw, t, lds, a.W + (size_t)p * a.n3);
+        a_load_T(vw, t, lds, a.W, (size_t)p * a.n3);
         LineFft<real, N, +1>::run(vw, t.j0, t.line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
     cplx* tw = lds + 2 * tp::A_HALF;
     a_load_twiddles(tw, a.tw);
     cplx v[E];
-    a_load_T(v, t, lds, a.W + (size_t)p * a.n3);
+    a_load_T(v, t, lds, a.W, (size_t)p * a.n3);
     LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
 
     real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
 
 // Pass B: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
 // simulation_object.rs:1076-1102), and both stages back, on one half-run of T in place.
-__global__ __launch_bounds__(tp::B_THREADS) void k_poisson_b(PoisArgs a) {
+__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_poisson_b(PoisArgs a) {
     constexpr int N = tp::N, LINE = tp::B_LINE;
     __shared__ real plane[32 * LINE];
     __shared__ cplx tw[N];
@@ -918,12 +922,15 @@ __global__ __launch_bounds__(tp::B_THREADS) void k_poisson_b(PoisArgs a) {
     const int bx = blockIdx.x;
     const int half = (bx >> 3) & 1, run = ((bx >> 4) << 3) | (bx & 7);   // partner half-run 8 blocks away
     const int tpi = run >> 6, kxh = run & 63;                            // t', kx >> 2
-    cplx* __restrict__ w = a.W + (size_t)p * a.n3 + (size_t)run * 16384 + half * 4 + (tid >> 2) * 8 + (tid & 3);
+    // uniform base per q plus one 32-bit lane offset: keeps the sixteen addresses out of the vector registers
+    cplx* __restrict__ wbase = a.W;
+    const size_t wrun = (size_t)p * a.n3 + (size_t)run * 16384 + half * 4;
+    const unsigned woff = (unsigned)((tid >> 2) * 8 + (tid & 3));
 
     // role b: this thread is (z = tid >> 1, kx bit 0 = tid & 1) and holds the 16 values b (then b')
     cplx v[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = w[q * 1024];
+    for (int q = 0; q < 16; ++q) v[q] = (wbase + (wrun + q * 1024))[woff];
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], a.tw[(q * tpi) & (N - 1)]);
     dft<16, -1, real>(v);
@@ -974,8 +981,9 @@ __global__ __launch_bounds__(tp::B_THREADS) void k_poisson_b(PoisArgs a) {
     dft<16, +1, real>(v);
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], a.tw[(q * tpi) & (N - 1)]);
+    const unsigned woff2 = fresh(woff);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) w[q * 1024] = v[q];
+    for (int q = 0; q < 16; ++q) (wbase + (wrun + q * 1024))[woff2] = v[q];
 }
 
 // Reduce the per-workgroup partials of one stream in a fixed order (bitwise reproducible).
