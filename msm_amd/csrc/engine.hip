@@ -907,83 +907,332 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
     }
 }
 
-// Pass B: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
+// Pass-B role changes through one real LDS plane (32 padded z lines).
+//   column role: thread = (z = tid >> 1, kx bit 0 = tid & 1), holds the 16 values b (or b')
+//   line role:   thread = (j0 = tid & 15, line L = tid >> 4 = 2 b' + kx bit 0), holds z = j0 + 16 q
+struct RolesB {
+    int j0, L;
+    real* colw;
+    real* line;
+    __device__ __forceinline__ RolesB(real* plane) {
+        const int tid = threadIdx.x;
+        j0 = tid & 15; L = tid >> 4;
+        colw = plane + (tid & 1) * tp::B_LINE + lds_pad(tid >> 1);
+        line = plane + L * tp::B_LINE;
+    }
+};
+// column -> line; the plane must be free on entry and is free again on return
+__device__ __forceinline__ void b_to_lines(cplx (&v)[16], const RolesB& r) {
+    constexpr int CS = 2 * tp::B_LINE;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r.colw[q * CS] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = r.line[lds_pad(r.j0 + 16 * q)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r.colw[q * CS] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = r.line[lds_pad(r.j0 + 16 * q)];
+    __syncthreads();
+}
+// line -> column; the plane must be free on entry; other threads may still read it on return
+__device__ __forceinline__ void b_to_cols(cplx (&v)[16], const RolesB& r) {
+    constexpr int CS = 2 * tp::B_LINE;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r.line[lds_pad(r.j0 + 16 * q)] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = r.colw[q * CS];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r.line[lds_pad(r.j0 + 16 * q)] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = r.colw[q * CS];
+}
+// blockIdx.x -> (half-run, run): partner half-runs sit 8 blocks apart
+struct RunB {
+    int half, run, tpi, kxh;
+    __device__ __forceinline__ RunB() {
+        const int bx = blockIdx.x;
+        half = (bx >> 3) & 1; run = ((bx >> 4) << 3) | (bx & 7);
+        tpi = run >> 6; kxh = run & 63;      // t', kx >> 2
+    }
+};
+// T (column role) -> inner y stage -> line role -> z transform; v ends as kz = j0 + 16 q
+__device__ __forceinline__ void b_forward(cplx (&v)[16], const cplx* __restrict__ T, size_t trun, unsigned toff,
+                                          int tpi, const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = (T + (trun + q * 1024))[toff];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
+    dft<16, -1, real>(v);
+    b_to_lines(v, r);
+    LineFftSplit<real, tp::N, -1>::run(v, r.j0, r.line, tw_lds);
+}
+// the way back; the plane must be free on entry
+__device__ __forceinline__ void b_inverse(cplx (&v)[16], cplx* __restrict__ T, size_t trun, unsigned toff, int tpi,
+                                          const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
+    LineFftSplit<real, tp::N, +1>::run(v, r.j0, r.line, tw_lds);
+    __syncthreads();
+    b_to_cols(v, r);
+    dft<16, +1, real>(v);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
+    const unsigned toff2 = fresh(toff);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) (T + (trun + q * 1024))[toff2] = v[q];
+}
+
+// Pass B of the Poisson solve: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
 // simulation_object.rs:1076-1102), and both stages back, on one half-run of T in place.
 __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_poisson_b(PoisArgs a) {
-    constexpr int N = tp::N, LINE = tp::B_LINE;
-    __shared__ real plane[32 * LINE];
+    constexpr int N = tp::N;
+    __shared__ real plane[32 * tp::B_LINE];
     __shared__ cplx tw[N];
     const int tid = threadIdx.x;
     const int p = blockIdx.y;
     const int sa = a.s0 + 2 * p, sb = sa + 1;
     if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
     if (tid < N) tw[tid] = a.tw[tid];   // first read is behind the exchange barriers
+    const RunB rb;
+    const RolesB r(plane);
+    const size_t trun = (size_t)p * a.n3 + (size_t)rb.run * 16384 + rb.half * 4;
+    const unsigned toff = (unsigned)((tid >> 2) * 8 + (tid & 3));
 
-    const int bx = blockIdx.x;
-    const int half = (bx >> 3) & 1, run = ((bx >> 4) << 3) | (bx & 7);   // partner half-run 8 blocks away
-    const int tpi = run >> 6, kxh = run & 63;                            // t', kx >> 2
-    // uniform base per q plus one 32-bit lane offset: keeps the sixteen addresses out of the vector registers
-    cplx* __restrict__ wbase = a.W;
-    const size_t wrun = (size_t)p * a.n3 + (size_t)run * 16384 + half * 4;
-    const unsigned woff = (unsigned)((tid >> 2) * 8 + (tid & 3));
-
-    // role b: this thread is (z = tid >> 1, kx bit 0 = tid & 1) and holds the 16 values b (then b')
     cplx v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = (wbase + (wrun + q * 1024))[woff];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], a.tw[(q * tpi) & (N - 1)]);
-    dft<16, -1, real>(v);
-
-    // role z: this thread is (j0 = tid & 15, line L = tid >> 4 = 2 b' + kx bit 0) and holds z = j0 + 16 q
-    real* colw = plane + (tid & 1) * LINE + lds_pad(tid >> 1);
-    const int j0 = tid & 15, L = tid >> 4;
-    real* line = plane + L * LINE;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) colw[q * 2 * LINE] = v[q].x;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].x = line[lds_pad(j0 + 16 * q)];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) colw[q * 2 * LINE] = v[q].y;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].y = line[lds_pad(j0 + 16 * q)];
-    __syncthreads();
-
-    LineFftSplit<real, N, -1>::run(v, j0, line, tw);
-
-    const int kx = (kxh << 2) | (half << 1) | (L & 1), ky = tpi + 16 * (L >> 1);
+    b_forward(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
+    const int kx = (rb.kxh << 2) | (rb.half << 1) | (r.L & 1), ky = rb.tpi + 16 * (r.L >> 1);
     const real kxy = a.ksq[kx] + a.ksq[ky];   // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const real k2 = (kxy + a.ksq[j0 + 16 * q]) * a.fourpi2;
+        const real k2 = (kxy + a.ksq[r.j0 + 16 * q]) * a.fourpi2;
         const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
         v[q] = cscale(v[q], g);
     }
     __syncthreads();
-    LineFftSplit<real, N, +1>::run(v, j0, line, tw);
+    b_inverse(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
+}
+
+// Pass B of the psi transforms.  psi_k is kept as P[kx][ky][kz] (kz contiguous), which is what the
+// line role of this pass reads and writes in 256-byte rows.
+//   PB_FWD: T -> P                      (psi_k = F psi, unitary scale on store)
+//   PB_INV: P -> T, optional drift      (first pass of psi = F^-1[D psi_k], simulation_object.rs:504-528)
+//   PB_MID: T -> D F[.] -> P, aliased-mass partial, and straight back to T
+//           (simulation_object.rs:552-581 and check_alias :1249-1280)
+struct PsiBArgs {
+    cplx* T;             // [batch][n3], local stream index
+    cplx* P;             // [n_streams][n3], global stream index
+    size_t n3;
+    const int* active;   // may be null
+    int s0;
+    const cplx* tw;
+    const cplx* drift;   // [n_streams][N]
+    const real* ksq;
+    real scale, alias_cut, fourpi2;
+    double* partial;     // [n_streams][ntiles]
+    int ntiles;
+};
+enum { PB_FWD = 0, PB_INV = 1, PB_MID = 2 };
+
+template <int MODE, int DRIFT>
+__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_b(PsiBArgs a) {
+    constexpr int N = tp::N;
+    __shared__ real plane[32 * tp::B_LINE];
+    __shared__ cplx tw[N];
+    __shared__ double red[MODE == PB_MID ? 8 : 1];
+    const int tid = threadIdx.x;
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (a.active != nullptr && !a.active[sg]) return;
+    if (tid < N) tw[tid] = a.tw[tid];
+    const RunB rb;
+    const RolesB r(plane);
+    const size_t trun = (size_t)ls * a.n3 + (size_t)rb.run * 16384 + rb.half * 4;
+    const unsigned toff = (unsigned)((tid >> 2) * 8 + (tid & 3));
+    const int kx = (rb.kxh << 2) | (rb.half << 1) | (r.L & 1), ky = rb.tpi + 16 * (r.L >> 1);
+    cplx* __restrict__ prow = a.P + (size_t)sg * a.n3 + ((size_t)kx * N + ky) * N + r.j0;
+    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+
+    cplx v[16];
+    if constexpr (MODE != PB_INV) {
+        b_forward(v, a.T, trun, toff, rb.tpi, r, tw, a.tw);
+        if constexpr (MODE == PB_MID || DRIFT) {
+            const cplx dxy = cmul(d[kx], d[ky]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(dxy, d[r.j0 + 16 * q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = cscale(v[q], a.scale);
+            prow[16 * q] = v[q];
+        }
+        if constexpr (MODE == PB_MID) {
+            const real kxy = a.ksq[kx] + a.ksq[ky];
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const real k2 = (kxy + a.ksq[r.j0 + 16 * q]) * a.fourpi2;
+                if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();   // also frees the plane for the way back
+            if (tid == 0) {
+                double tot = red[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) tot += red[w];
+                a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = prow[16 * q];
+        if constexpr (DRIFT) {
+            const cplx dxy = cmul(d[kx], d[ky]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(dxy, d[r.j0 + 16 * q]));
+        }
+    }
+    if constexpr (MODE != PB_FWD) b_inverse(v, a.T, trun, toff, rb.tpi, r, tw, a.tw);
+}
+
+// Pass A of a plain psi transform: natural layout <-> T.
+//   SGN = -1: x lines forward, outer y stage, store T;   SGN = +1: the inverse, scaled, to the natural layout.
+template <int SGN>
+__global__ __launch_bounds__(tp::A_THREADS) void k_psi_a(PsiArgs a) {
+    constexpr int N = tp::N, E = 16, TPL = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (a.active != nullptr && !a.active[sg]) return;
+    const size_t so = (size_t)(a.src_local ? ls : sg) * a.n3, dof = (size_t)(a.dst_local ? ls : sg) * a.n3;
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
+    cplx v[E];
+    if constexpr (SGN < 0) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = a.src[so + t.base + t.j0 + TPL * q];
+        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        a_store_T(v, t, lds, a.dst, dof);
+    } else {
+        a_load_T(v, t, lds, a.src, so);
+        LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) a.dst[dof + t.base + t.j0 + TPL * q] = cscale(v[q], a.scale);
+    }
+}
+
+// k_invx_rho with psi arriving in T (after pass B of the inverse transform): no drift factor left to apply.
+template <int DENS>
+__global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho3(PoisArgs a) {
+    constexpr int E = 16, TPL = 16, N = tp::N;
+    __shared__ cplx lds[tp::A_LDS];
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
     __syncthreads();
 
+    double dacc[DENS ? E : 1];
+    if constexpr (DENS) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) line[lds_pad(j0 + 16 * q)] = v[q].x;
-    __syncthreads();
+        for (int q = 0; q < E; ++q) dacc[q] = 0.0;
+    }
+    const int pairs = (a.nb + 1) / 2;
+    for (int p = 0; p < pairs; ++p) {
+        const int sa = a.s0 + 2 * p, sb = sa + 1;
+        const bool act_a = a.active[sa] != 0;
+        const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+        if (!act_a && !act_b) continue;   // uniform over the workgroup
+        real rho[2][E];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].x = colw[q * 2 * LINE];
-    __syncthreads();
+        for (int h = 0; h < 2; ++h) {
+            const bool act = h == 0 ? act_a : act_b;
+            if (act) {
+                cplx v[E];
+                a_load_T(v, t, lds, a.X, (size_t)(2 * p + h) * a.n3);
+                LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) line[lds_pad(j0 + 16 * q)] = v[q].y;
-    __syncthreads();
+                for (int q = 0; q < E; ++q) {
+                    v[q] = cscale(v[q], a.scale);
+                    const real m2 = v[q].x * v[q].x + v[q].y * v[q].y;
+                    rho[h][q] = a.mass_factor * m2;
+                    if constexpr (DENS) dacc[q] += (double)m2;
+                }
+                __syncthreads();   // exchange reads done before the next LDS writes
+            } else {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].y = colw[q * 2 * LINE];
+                for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
+            }
+        }
+        cplx v[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
+        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
+        __syncthreads();
+    }
+    if constexpr (DENS) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];
+    }
+}
 
-    dft<16, +1, real>(v);
+// k_kick_fwdx with psi in T on both sides: phi_a + i phi_b and the half-drifted psi come back through
+// the outer y stage and the inverse x lines, the kicked psi leaves through forward x and the outer y stage.
+__global__ __launch_bounds__(tp::A_THREADS) void k_kick3(PoisArgs a, const real* __restrict__ kick) {
+    constexpr int N = tp::N, E = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    const int p = blockIdx.y;
+    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const bool act_a = a.active[sa] != 0;
+    const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+    if (!act_a && !act_b) return;
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    a_load_twiddles(tw, a.tw);
+
+    real phi[2][E];
+    {
+        cplx vw[E];
+        a_load_T(vw, t, lds, a.W, (size_t)p * a.n3);
+        LineFft<real, N, +1>::run(vw, t.j0, t.line, tw);
 #pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], a.tw[(q * tpi) & (N - 1)]);
-    const unsigned woff2 = fresh(woff);
+        for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
+    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) (wbase + (wrun + q * 1024))[woff2] = v[q];
+    for (int h = 0; h < 2; ++h) {
+        const bool act = h == 0 ? act_a : act_b;
+        if (!act) continue;   // uniform over the workgroup
+        const int sg = h == 0 ? sa : sb;
+        const real kc = kick[sg];
+        const size_t xo = (size_t)(2 * p + h) * a.n3;
+        __syncthreads();
+        cplx v[E];
+        a_load_T(v, t, lds, a.X, xo);
+        LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            real sn, cs;
+            sincos_t(kc * phi[h][q], &sn, &cs);
+            v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
+        }
+        __syncthreads();
+        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        a_store_T(v, t, lds, a.Xout, xo);
+    }
+}
+
+// dst[z][y][x] = src[x][y][z] for one N^3 grid (psi_k downloads from the P[kx][ky][kz] layout)
+__global__ __launch_bounds__(256) void k_transpose_xz(const cplx* __restrict__ src, cplx* __restrict__ dst, int N) {
+    __shared__ cplx tile[32][33];
+    const int y = blockIdx.z, x0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = src[((size_t)(x0 + i) * N + y) * N + z0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) dst[((size_t)(z0 + i) * N + y) * N + x0 + tx] = tile[tx][i];
 }
 
 // Reduce the per-workgroup partials of one stream in a fixed order (bitwise reproducible).
@@ -1252,6 +1501,9 @@ class Engine final : public IEngine {
     void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
     // act = all_active_ solves for finished streams too (standalone msm_potential)
     void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act);
+    // two-pass psi transforms (psi2_): pass B between P and the T-layout scratch X_, pass A between T and a natural grid
+    void psi_b(int mode, bool drift, int s0, int n, const int* act, int kind);
+    void psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act);
     void first_step_init(int s0, int nb);
     void step_front(int s0, int nb);
     void step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
@@ -1286,6 +1538,8 @@ class Engine final : public IEngine {
     std::vector<int> host_active_;
     bool fourier_ = false;   // P_ holds psi_k (after the first step)
     bool two_pass_ = false;  // Poisson solve in two passes over the work array (N = 256, double)
+    bool psi2_ = false;      // psi transforms in two passes as well; psi_k is then kept as P[kx][ky][kz]
+    cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
@@ -1400,8 +1654,11 @@ int Engine::init(std::string& err) {
     c_.inv_n3 = (real)(1.0 / ((double)N_ * N_ * N_));
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
-    two_pass_ = (N_ == tp::N) && sizeof(real) == 8;
-    if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;
+    two_pass_ = psi2_ = (N_ == tp::N) && sizeof(real) == 8;
+    if (const char* e = getenv("MSM_TWO_PASS")) {   // 0: three passes per transform, 1: two-pass Poisson only
+        two_pass_ = two_pass_ && atoi(e) >= 1;
+        psi2_ = psi2_ && atoi(e) >= 2;
+    }
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
@@ -1421,6 +1678,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(dmalloc((void**)&P_, grid_bytes * ns_));
     HIP_TRY(dmalloc((void**)&X_, grid_bytes * (size_t)(2 * pairs)));
     HIP_TRY(dmalloc((void**)&W_, grid_bytes * pairs));
+    HIP_TRY(dmalloc((void**)&stage_, grid_bytes));
     HIP_TRY(dmalloc((void**)&PHI_, n3_ * sizeof(real) * (size_t)(2 * pairs)));
     HIP_TRY(dmalloc((void**)&partial_, sizeof(double) * (size_t)ns_ * ntiles_));
     HIP_TRY(dmalloc((void**)&tw_, sizeof(cplx) * N_));
@@ -1591,11 +1849,44 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
     poisson_tail(s0, nb, store_phi, track_max, true, act);
 }
 
+void Engine::psi_b(int mode, bool drift, int s0, int n, const int* act, int kind) {
+    PsiBArgs b{};
+    b.T = X_; b.P = P_; b.n3 = n3_; b.active = act; b.s0 = s0; b.tw = tw_; b.drift = st_.drift; b.ksq = ksq_;
+    b.scale = c_.unit_scale; b.alias_cut = c_.alias_cut; b.fourpi2 = c_.fourpi2; b.partial = partial_; b.ntiles = ntiles_;
+    if constexpr (sizeof(real) == 8) {
+        const dim3 grid(tp::B_BLOCKS, (unsigned)n), block(tp::B_THREADS);
+        timed(kind, [&] {
+            if (mode == PB_FWD) k_psi_b<PB_FWD, 0><<<grid, block, 0, stream_>>>(b);
+            else if (mode == PB_MID) k_psi_b<PB_MID, 1><<<grid, block, 0, stream_>>>(b);
+            else if (drift) k_psi_b<PB_INV, 1><<<grid, block, 0, stream_>>>(b);
+            else k_psi_b<PB_INV, 0><<<grid, block, 0, stream_>>>(b);
+        });
+    }
+}
+
+void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act) {
+    PsiArgs a{};
+    a.src = src; a.dst = dst; a.n3 = n3_; a.active = act; a.s0 = s0; a.src_local = src_local; a.dst_local = dst_local;
+    a.tw = tw_; a.scale = c_.unit_scale;
+    if constexpr (sizeof(real) == 8) {
+        const dim3 grid(tp::A_TILES, (unsigned)n), block(tp::A_THREADS);
+        timed(PK_PLAIN, [&] {
+            if (sgn < 0) k_psi_a<-1><<<grid, block, 0, stream_>>>(a);
+            else k_psi_a<+1><<<grid, block, 0, stream_>>>(a);
+        });
+    }
+}
+
 // Before the first step P_ holds psi: size the first timestep from it (simulation_object.rs:497)
 // and move the state to Fourier space (psi_k = F psi, :477-479).
 void Engine::first_step_init(int s0, int nb) {
     poisson_from_psi(P_, false, s0, nb, false, true, st_.active);
-    fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
+    if (psi2_) {
+        psi_a(-1, P_, false, X_, true, s0, nb, st_.active);
+        psi_b(PB_FWD, false, s0, nb, st_.active, PK_PLAIN);
+    } else {
+        fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
+    }
 }
 
 // timestep (simulation_object.rs:500); max|phi| of psi(t) was left by the previous step's tail
@@ -1610,6 +1901,28 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.drift = st_.drift;
     a.phi = PHI_; a.kick = st_.kick; a.scale = (real)1;
     PoisArgs p = pois_args(s0, nb, st_.active);
+
+    if (psi2_) {
+        if constexpr (sizeof(real) == 8) {
+            const dim3 gridA(tp::A_TILES), gridAp(tp::A_TILES, (unsigned)((nb + 1) / 2)), blockA(tp::A_THREADS);
+            // psi = F^-1[ D psi_k ]: pass B with the whole drift factor, pass A fused with rho and the Poisson pass A
+            psi_b(PB_INV, true, s0, nb, st_.active, PK_INV_Z);
+            timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p); });
+            poisson_tail(s0, nb, false, false, false);
+            // kick between the two A passes; pass B applies the second drift, stores psi_k and turns round
+            timed(PK_FWD_X, [&] { k_kick3<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); });
+            psi_b(PB_MID, true, s0, nb, st_.active, PK_FWDZ_INVZ);
+            k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::B_BLOCKS, s0, st_.active);
+            k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+            p.dens = step_dens_;
+            timed(PK_INVX_RHO, [&] {
+                if (step_dens_) k_invx_rho3<1><<<gridA, blockA, 0, stream_>>>(p);
+                else k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p);
+            });
+            poisson_tail(s0, nb, false, true);
+        }
+        return;
+    }
 
     // psi = F^-1[ D psi_k ]  (z, y plain passes; x fused with rho and the Poisson forward x pass)
     a.src = P_; a.src_local = 0; a.dst = X_; a.dst_local = 1;
@@ -1757,7 +2070,14 @@ int Engine::potential(int first, int count, std::string& err) {
     if (first < 0 || count < 1 || first + count > ns_) { err = "stream range out of bounds"; return MSM_ERR_INVALID; }
     if (count > 2 * ((batch_ + 1) / 2)) { err = "count exceeds the batch size"; return MSM_ERR_INVALID; }
     if (in_step_) { err = "msm_potential inside an open msm_step_begin"; return MSM_ERR_STATE; }
-    if (fourier_) {
+    if (fourier_ && psi2_) {
+        psi_b(PB_INV, false, first, count, nullptr, PK_PLAIN);
+        if constexpr (sizeof(real) == 8) {
+            const PoisArgs p = pois_args(first, count, all_active_);
+            timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+        }
+        poisson_tail(first, count, true, true, true, all_active_);
+    } else if (fourier_) {
         fft3_plain(P_, false, X_, true, first, count, +1, nullptr);
         poisson_from_psi(X_, true, first, count, true, true, all_active_);
     } else {
@@ -1822,10 +2142,20 @@ int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
     const cplx* src = P_ + (size_t)s * n3_;
     if (!kspace && fourier_) {
         // psi = F^-1 psi_k (simulation_object.rs:581), materialised on demand in the batch scratch
-        fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
+        if (psi2_) {
+            psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
+            psi_a(+1, X_, true, W_, true, s, 1, nullptr);
+            src = W_;
+        } else {
+            fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
+            src = X_;
+        }
+    } else if (kspace && psi2_) {
+        const unsigned nb32 = (unsigned)(N_ / 32);
+        k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(src, X_, N_);
         src = X_;
     }
-    real* stage = (real*)W_;   // two real planes fit one complex scratch grid
+    real* stage = (real*)stage_;   // two real planes fit one complex grid
     k_split<<<2048, 256, 0, stream_>>>(src, stage, stage + n3_, n3_);
     HIP_TRY(hipMemcpyAsync(re, stage, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(im, stage + n3_, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
@@ -1850,6 +2180,12 @@ int Engine::density_sum(void* dev_out, std::string& err) {
     if (in_step_) { err = "msm_density_sum inside an open msm_step_begin"; return MSM_ERR_STATE; }
     if (!fourier_) {
         k_density_sum<<<2048, 256, 0, stream_>>>(P_, n3_, ns_, (double*)dev_out, 0);
+    } else if (psi2_) {
+        for (int s = 0; s < ns_; ++s) {
+            psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
+            psi_a(+1, X_, true, W_, true, s, 1, nullptr);
+            k_density_sum<<<2048, 256, 0, stream_>>>(W_, n3_, 1, (double*)dev_out, s > 0 ? 1 : 0);
+        }
     } else {
         for (int s0 = 0; s0 < ns_; s0 += batch_) {
             const int nb = std::min(batch_, ns_ - s0);
