@@ -150,6 +150,34 @@ __device__ __forceinline__ float recip_t(float x) { return 1.0f / x; }
 // rebuilt where they are used instead of being kept (or spilled) since their first use.
 __device__ __forceinline__ unsigned fresh(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
+// Buffer addressing for the tile loads and stores whose sixteen accesses lie far apart: descriptor
+// (wave-uniform base) + one 32-bit lane offset + a scalar offset per access, all in bytes and below
+// 4 GiB in total.  No 64-bit address pair per access has to live in vector registers.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+using bufdesc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ bufdesc buf_of(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ void buf_ld(double2& v, bufdesc r, unsigned lane_bytes, unsigned uni_bytes) {
+    const f64x2 d = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uni_bytes, 0));
+    v.x = d.x; v.y = d.y;
+}
+__device__ __forceinline__ void buf_ld(float2& v, bufdesc r, unsigned lane_bytes, unsigned uni_bytes) {
+    const f32x2 d = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_bytes, (int)uni_bytes, 0));
+    v.x = d.x; v.y = d.y;
+}
+__device__ __forceinline__ void buf_st(double2 v, bufdesc r, unsigned lane_bytes, unsigned uni_bytes) {
+    f64x2 d; d.x = v.x; d.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), r, (int)lane_bytes, (int)uni_bytes, 0);
+}
+__device__ __forceinline__ void buf_st(float2 v, bufdesc r, unsigned lane_bytes, unsigned uni_bytes) {
+    f32x2 d; d.x = v.x; d.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, d), r, (int)lane_bytes, (int)uni_bytes, 0);
+}
+
 // max of two values per thread over the workgroup in one pass: wavefront shuffles, then one LDS
 // round over the (at most 16) wavefronts.  NaN wins so that a poisoned potential stays visible.
 __device__ __forceinline__ double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
@@ -217,7 +245,9 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
     using G = Geom<N, AX>;
     if constexpr (G::USES_LDS) {
         for (int i = threadIdx.x; i < N; i += G::THREADS) tw_lds[i] = tw_g[i];
-        // visibility: the first use is after the stage-0 exchange barrier
+        // visibility: x lines exchange inside their wavefront, so the table needs its own barrier;
+        // on the strided axes the first use is after the stage-0 exchange barrier
+        if constexpr (AX == 0) lds_barrier();
     }
 }
 
@@ -291,7 +321,7 @@ __global__ __launch_bounds__((Geom<N, AX>::THREADS)) void k_psi_pass(PsiArgs a) 
         }
     }
 
-    LineFft<real, N, SGN>::run(v, t.j0, line, tw);
+    LineFft<real, N, SGN, AX == 0>::run(v, t.j0, line, tw);
 
 #pragma unroll
     for (int q = 0; q < E; ++q) {
@@ -428,7 +458,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_rho_pass(PoisArgs a) 
             v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), (real)0);
         }
     }
-    LineFft<real, N, -1>::run(v, t.j0, line, tw);
+    LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
 #pragma unroll
     for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
 }
@@ -475,7 +505,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_invx_rho(PoisArgs a) 
 #pragma unroll
                     for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
                 }
-                LineFft<real, N, +1>::run(v, t.j0, line, tw);
+                LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
                 cplx* __restrict__ xo = a.Xout + (size_t)(2 * p + h) * a.n3;
 #pragma unroll
                 for (int q = 0; q < E; ++q) {
@@ -485,7 +515,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_invx_rho(PoisArgs a) 
                     rho[h][q] = a.mass_factor * m2;
                     if constexpr (DENS) dacc[q] += (double)m2;
                 }
-                if constexpr (G::USES_LDS) __syncthreads();   // exchange reads done before the next run writes
+                if constexpr (G::USES_LDS) exch_sync<true>();   // exchange reads done before the next run writes
             } else {
 #pragma unroll
                 for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
@@ -494,11 +524,11 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_invx_rho(PoisArgs a) 
         cplx v[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
-        LineFft<real, N, -1>::run(v, t.j0, line, tw);
+        LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
         cplx* __restrict__ w = a.W + (size_t)p * a.n3;
 #pragma unroll
         for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
-        if constexpr (G::USES_LDS) __syncthreads();
+        if constexpr (G::USES_LDS) exch_sync<true>();
     }
     if constexpr (DENS) {
 #pragma unroll
@@ -534,7 +564,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a,
         cplx vw[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
-        LineFft<real, N, +1>::run(vw, t.j0, line, tw);
+        LineFft<real, N, +1, true>::run(vw, t.j0, line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
     }
@@ -546,21 +576,21 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a,
         cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
         const cplx* __restrict__ d = a.drift + (size_t)sg * N;
         const real kc = kick[sg];
-        if constexpr (G::USES_LDS) __syncthreads();   // also keeps the psi loads below the previous transform
+        if constexpr (G::USES_LDS) exch_sync<true>();   // also keeps the psi loads below the previous transform
         cplx v[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-        LineFft<real, N, +1>::run(v, t.j0, line, tw);
+        LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             real sn, cs;
             sincos_t(kc * phi[h][q], &sn, &cs);
             v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
         }
-        if constexpr (G::USES_LDS) __syncthreads();
-        LineFft<real, N, -1>::run(v, t.j0, line, tw);
+        if constexpr (G::USES_LDS) exch_sync<true>();
+        LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
     }
@@ -596,7 +626,7 @@ __global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_poisson_mid(PoisArgs 
         const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
         v[q] = cscale(v[q], g);
     }
-    if constexpr (G::USES_LDS) __syncthreads();  // all exchange reads of the forward run are done
+    if constexpr (G::USES_LDS) lds_barrier();  // all exchange reads of the forward run are done
     LineFft<real, N, +1>::run(v, t.j0, line, tw);
 #pragma unroll
     for (int q = 0; q < E; ++q) w[t.base + (size_t)(t.j0 + TPL * q) * t.stride] = v[q];
@@ -624,7 +654,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
     cplx v[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) v[q] = w[t.base + t.j0 + TPL * q];
-    LineFft<real, N, +1>::run(v, t.j0, line, tw);
+    LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
 
     real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
     real* __restrict__ pb = a.PHI + (size_t)(2 * p + 1) * a.n3;
@@ -672,6 +702,7 @@ constexpr int A_TILES = 2048;                      // zh (128) x b (16)
 constexpr size_t T_TP = (size_t)64 * 16384;        // stride of t' in T
 constexpr int B_THREADS = 512, B_LINE = 272;       // reals per padded z line; 272 = 16 mod 32 keeps line pairs on disjoint banks
 constexpr int B_BLOCKS = 2 * 1024;                 // two half-runs per (t', kx >> 2)
+constexpr int MAX_BATCH = 256;                     // streams per sub-batch the A kernels keep flags for
 }
 
 struct TileA {
@@ -692,10 +723,9 @@ struct TileA {
 // radix-16 stage over t, store to T.  Barriers inside; all 512 threads call.
 __device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* lds, cplx* __restrict__ wT, size_t grid_off) {
     const int tid = threadIdx.x;
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.line[lds_pad(t.j0 + 16 * q)] = v[q];
-    __syncthreads();
+    for (int q = 0; q < 16; ++q) t.line[lds_pad(t.j0 + 16 * q)] = v[q];   // own line: ordered within the wave
+    lds_barrier();
     const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
     const cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
 #pragma unroll
@@ -706,25 +736,42 @@ __device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* l
     for (int q = 0; q < 16; ++q) (wT + (grid_off + (size_t)q * tp::T_TP))[off] = v[q];
 }
 
-// The way back: load from T, inverse radix-16 stage over t', column role -> line role.
-__device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* lds, const cplx* __restrict__ wT, size_t grid_off) {
+// The way back, in two halves so that the loads can be issued ahead of their use: a_fetch_T only
+// loads (column role); a_cols_to_lines does the inverse radix-16 stage over t' and the column role ->
+// line role exchange (one barrier; LDS lines must not be in use by other wavefronts on entry).
+// The sixteen loads lie 16 MiB apart; one running address pair serves them all.
+typedef real real2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) real2v* gcptr;
+__device__ __forceinline__ void a_fetch_T(cplx (&v)[16], const TileA& t, const cplx* __restrict__ wT, size_t grid_off) {
+    const int tid = threadIdx.x;
+    gcptr p = (gcptr)(wT + grid_off + (size_t)(((tid >> 3) * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7)));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const real2v d = *p;
+        v[q] = mk<real>(d.x, d.y);
+        p += tp::T_TP;
+        asm volatile("" : "+v"(p));
+    }
+}
+__device__ __forceinline__ void a_cols_to_lines(cplx (&v)[16], const TileA& t, cplx* lds) {
     const int tid = threadIdx.x;
     const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
-    const unsigned off = (unsigned)((kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = (wT + (grid_off + (size_t)q * tp::T_TP))[off];
     dft<16, +1, real>(v);
     cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
 #pragma unroll
     for (int q = 0; q < 16; ++q) col[q * tp::A_LINE] = v[q];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = t.line[lds_pad(t.j0 + 16 * q)];
-    __syncthreads();
+}
+__device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* lds, const cplx* __restrict__ wT, size_t grid_off) {
+    a_fetch_T(v, t, wT, grid_off);
+    a_cols_to_lines(v, t, lds);
 }
 
 __device__ __forceinline__ void a_load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
     if (threadIdx.x < tp::N) tw_lds[threadIdx.x] = tw_g[threadIdx.x];
+    lds_barrier();
 }
 
 // k_invx_rho on A tiles: W leaves as T (x and outer-y stage done).
@@ -762,7 +809,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho2(PoisArgs a) {
 #pragma unroll
                     for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
                 }
-                LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+                LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
 #pragma unroll
                 for (int q = 0; q < E; ++q) {
                     v[q] = cscale(v[q], a.scale);
@@ -770,7 +817,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho2(PoisArgs a) {
                     rho[h][q] = a.mass_factor * m2;
                     if constexpr (DENS) dacc[q] += (double)m2;
                 }
-                __syncthreads();   // exchange reads done before the next run writes
+                lds_barrier();   // exchange reads done before the next run writes
             } else {
 #pragma unroll
                 for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
@@ -779,9 +826,9 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho2(PoisArgs a) {
         cplx v[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
-        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
         a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (DENS) {
 #pragma unroll
@@ -813,7 +860,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_rho_pass2(PoisArgs a) {
         }
         v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), rb);
     }
-    LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+    LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
     a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
 }
 
@@ -834,7 +881,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_kick_fwdx2(PoisArgs a, const 
     {
         cplx vw[E];
         a_load_T(vw, t, lds, a.W, (size_t)p * a.n3);
-        LineFft<real, N, +1>::run(vw, t.j0, t.line, tw);
+        LineFft<real, N, +1, true>::run(vw, t.j0, t.line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
     }
@@ -846,21 +893,21 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_kick_fwdx2(PoisArgs a, const 
         cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
         const cplx* __restrict__ d = a.drift + (size_t)sg * N;
         const real kc = kick[sg];
-        __syncthreads();   // also keeps the psi loads below the previous transform
+        lds_barrier();   // also keeps the psi loads below the previous transform
         cplx v[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-        LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+        LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             real sn, cs;
             sincos_t(kc * phi[h][q], &sn, &cs);
             v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
         }
-        __syncthreads();
-        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        lds_barrier();
+        LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
     }
@@ -881,7 +928,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
     a_load_twiddles(tw, a.tw);
     cplx v[E];
     a_load_T(v, t, lds, a.W, (size_t)p * a.n3);
-    LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+    LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
 
     real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
     real* __restrict__ pb = a.PHI + (size_t)(2 * p + 1) * a.n3;
@@ -926,29 +973,28 @@ __device__ __forceinline__ void b_to_lines(cplx (&v)[16], const RolesB& r) {
     constexpr int CS = 2 * tp::B_LINE;
 #pragma unroll
     for (int q = 0; q < 16; ++q) r.colw[q * CS] = v[q].x;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q].x = r.line[lds_pad(r.j0 + 16 * q)];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) r.colw[q * CS] = v[q].y;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q].y = r.line[lds_pad(r.j0 + 16 * q)];
-    __syncthreads();
 }
 // line -> column; the plane must be free on entry; other threads may still read it on return
 __device__ __forceinline__ void b_to_cols(cplx (&v)[16], const RolesB& r) {
     constexpr int CS = 2 * tp::B_LINE;
 #pragma unroll
     for (int q = 0; q < 16; ++q) r.line[lds_pad(r.j0 + 16 * q)] = v[q].x;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q].x = r.colw[q * CS];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) r.line[lds_pad(r.j0 + 16 * q)] = v[q].y;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q].y = r.colw[q * CS];
 }
@@ -964,26 +1010,26 @@ struct RunB {
 // T (column role) -> inner y stage -> line role -> z transform; v ends as kz = j0 + 16 q
 __device__ __forceinline__ void b_forward(cplx (&v)[16], const cplx* __restrict__ T, size_t trun, unsigned toff,
                                           int tpi, const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
+    const bufdesc rs = buf_of(T + trun);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = (T + (trun + q * 1024))[toff];
+    for (int q = 0; q < 16; ++q) buf_ld(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * 1024 * sizeof(cplx)));
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
     dft<16, -1, real>(v);
     b_to_lines(v, r);
-    LineFftSplit<real, tp::N, -1>::run(v, r.j0, r.line, tw_lds);
+    LineFftSplit<real, tp::N, -1, true>::run(v, r.j0, r.line, tw_lds);
 }
 // the way back; the plane must be free on entry
 __device__ __forceinline__ void b_inverse(cplx (&v)[16], cplx* __restrict__ T, size_t trun, unsigned toff, int tpi,
                                           const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
-    LineFftSplit<real, tp::N, +1>::run(v, r.j0, r.line, tw_lds);
-    __syncthreads();
+    LineFftSplit<real, tp::N, +1, true>::run(v, r.j0, r.line, tw_lds);
     b_to_cols(v, r);
     dft<16, +1, real>(v);
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
-    const unsigned toff2 = fresh(toff);
+    const bufdesc rs = buf_of(T + trun);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) (T + (trun + q * 1024))[toff2] = v[q];
+    for (int q = 0; q < 16; ++q) buf_st(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * 1024 * sizeof(cplx)));
 }
 
 // Pass B of the Poisson solve: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
@@ -1012,7 +1058,6 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
         const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
         v[q] = cscale(v[q], g);
     }
-    __syncthreads();
     b_inverse(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
 }
 
@@ -1079,7 +1124,7 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
             if ((tid & 63) == 0) red[tid >> 6] = acc;
-            __syncthreads();   // also frees the plane for the way back
+            lds_barrier();   // also frees the plane for the way back
             if (tid == 0) {
                 double tot = red[0];
 #pragma unroll
@@ -1115,64 +1160,70 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_psi_a(PsiArgs a) {
     if constexpr (SGN < 0) {
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = a.src[so + t.base + t.j0 + TPL * q];
-        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
+        LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
         a_store_T(v, t, lds, a.dst, dof);
     } else {
         a_load_T(v, t, lds, a.src, so);
-        LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
+        LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) a.dst[dof + t.base + t.j0 + TPL * q] = cscale(v[q], a.scale);
     }
 }
 
 // k_invx_rho with psi arriving in T (after pass B of the inverse transform): no drift factor left to apply.
+// The workgroup is alone on its CU (LDS), so it hides the load latency itself: stream b of a pair is
+// fetched while stream a is transformed, stream a of the next pair while W is.  The loop body is
+// straight-line code -- a finished stream is still transformed and its density dropped by a select,
+// the fetch past the end re-reads the last tile -- so that the number of loads in flight at every use
+// is a compile-time constant: the vector-memory counter retires in order, and a wait placed at a
+// branch merge has to assume the shorter path, i.e. drain everything.  For the same reason the stream
+// flags are read once into LDS: a flag load between a fetch and its use would wait for the fetch.
 template <int DENS>
 __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho3(PoisArgs a) {
     constexpr int E = 16, TPL = 16, N = tp::N;
     __shared__ cplx lds[tp::A_LDS];
+    __shared__ int act_lds[tp::MAX_BATCH + 2];
     const TileA t(blockIdx.x, threadIdx.x, lds);
     cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-    __syncthreads();
+    for (int i = threadIdx.x; i < tp::MAX_BATCH + 2; i += tp::A_THREADS) act_lds[i] = (i < a.nb) ? a.active[a.s0 + i] : 0;
+    a_load_twiddles(tw, a.tw);   // barrier inside
 
     double dacc[DENS ? E : 1];
     if constexpr (DENS) {
 #pragma unroll
         for (int q = 0; q < E; ++q) dacc[q] = 0.0;
     }
-    const int pairs = (a.nb + 1) / 2;
+    const int pairs = (a.nb + 1) / 2, last = a.nb - 1;
+    cplx va[E], vb[E];
+    a_fetch_T(va, t, a.X, 0);
     for (int p = 0; p < pairs; ++p) {
-        const int sa = a.s0 + 2 * p, sb = sa + 1;
-        const bool act_a = a.active[sa] != 0;
-        const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
-        if (!act_a && !act_b) continue;   // uniform over the workgroup
-        real rho[2][E];
+        const bool act_a = act_lds[2 * p] != 0, act_b = act_lds[2 * p + 1] != 0;   // uniform over the workgroup
+        a_fetch_T(vb, t, a.X, (size_t)min(2 * p + 1, last) * a.n3);
+        real rho0[E];
+        a_cols_to_lines(va, t, lds);
+        LineFft<real, N, +1, true>::run(va, t.j0, t.line, tw);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool act = h == 0 ? act_a : act_b;
-            if (act) {
-                cplx v[E];
-                a_load_T(v, t, lds, a.X, (size_t)(2 * p + h) * a.n3);
-                LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
-#pragma unroll
-                for (int q = 0; q < E; ++q) {
-                    v[q] = cscale(v[q], a.scale);
-                    const real m2 = v[q].x * v[q].x + v[q].y * v[q].y;
-                    rho[h][q] = a.mass_factor * m2;
-                    if constexpr (DENS) dacc[q] += (double)m2;
-                }
-                __syncthreads();   // exchange reads done before the next LDS writes
-            } else {
-#pragma unroll
-                for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
-            }
+        for (int q = 0; q < E; ++q) {
+            const cplx u = cscale(va[q], a.scale);
+            const real m2 = u.x * u.x + u.y * u.y;
+            rho0[q] = act_a ? a.mass_factor * m2 : (real)0;
+            if constexpr (DENS) dacc[q] += act_a ? (double)m2 : 0.0;
         }
-        cplx v[E];
+        lds_barrier();   // line role -> column writes of the next exchange
+        a_cols_to_lines(vb, t, lds);
+        LineFft<real, N, +1, true>::run(vb, t.j0, t.line, tw);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
-        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
-        a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
-        __syncthreads();
+        for (int q = 0; q < E; ++q) {
+            const cplx u = cscale(vb[q], a.scale);
+            const real m2 = u.x * u.x + u.y * u.y;
+            vb[q] = mk<real>(rho0[q], act_b ? a.mass_factor * m2 : (real)0);
+            if constexpr (DENS) dacc[q] += act_b ? (double)m2 : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a_fetch_T(va, t, a.X, (size_t)min(2 * p + 2, last) * a.n3);
+        LineFft<real, N, -1, true>::run(vb, t.j0, t.line, tw);
+        a_store_T(vb, t, lds, a.W, (size_t)p * a.n3);   // a pair of finished streams stores zeros
+        lds_barrier();
     }
     if constexpr (DENS) {
 #pragma unroll
@@ -1182,47 +1233,59 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho3(PoisArgs a) {
 
 // k_kick_fwdx with psi in T on both sides: phi_a + i phi_b and the half-drifted psi come back through
 // the outer y stage and the inverse x lines, the kicked psi leaves through forward x and the outer y stage.
+// Loads run ahead of their use (psi_a with W, psi_b from the middle of psi_a's turn); both streams of
+// the pair are always processed (see k_invx_rho3), only the store of a finished stream is skipped.
 __global__ __launch_bounds__(tp::A_THREADS) void k_kick3(PoisArgs a, const real* __restrict__ kick) {
     constexpr int N = tp::N, E = 16;
     __shared__ cplx lds[tp::A_LDS];
     const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
+    const int sa = a.s0 + 2 * p;
+    const bool has_b = 2 * p + 1 < a.nb;
+    const int sb = has_b ? sa + 1 : sa;
     const bool act_a = a.active[sa] != 0;
-    const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
+    const bool act_b = has_b && a.active[sb] != 0;
     if (!act_a && !act_b) return;
+    const real kca = kick[sa], kcb = kick[sb];
+    const size_t xa = (size_t)(2 * p) * a.n3, xb = (size_t)(has_b ? 2 * p + 1 : 2 * p) * a.n3;
     const TileA t(blockIdx.x, threadIdx.x, lds);
     cplx* tw = lds + 2 * tp::A_HALF;
     a_load_twiddles(tw, a.tw);
 
+    cplx va[E], vb[E];
     real phi[2][E];
     {
         cplx vw[E];
-        a_load_T(vw, t, lds, a.W, (size_t)p * a.n3);
-        LineFft<real, N, +1>::run(vw, t.j0, t.line, tw);
+        a_fetch_T(vw, t, a.W, (size_t)p * a.n3);
+        a_fetch_T(va, t, a.X, xa);
+        a_cols_to_lines(vw, t, lds);
+        LineFft<real, N, +1, true>::run(vw, t.j0, t.line, tw);
 #pragma unroll
         for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
+        lds_barrier();
     }
+    a_cols_to_lines(va, t, lds);
+    LineFft<real, N, +1, true>::run(va, t.j0, t.line, tw);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool act = h == 0 ? act_a : act_b;
-        if (!act) continue;   // uniform over the workgroup
-        const int sg = h == 0 ? sa : sb;
-        const real kc = kick[sg];
-        const size_t xo = (size_t)(2 * p + h) * a.n3;
-        __syncthreads();
-        cplx v[E];
-        a_load_T(v, t, lds, a.X, xo);
-        LineFft<real, N, +1>::run(v, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            real sn, cs;
-            sincos_t(kc * phi[h][q], &sn, &cs);
-            v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
-        }
-        __syncthreads();
-        LineFft<real, N, -1>::run(v, t.j0, t.line, tw);
-        a_store_T(v, t, lds, a.Xout, xo);
+    for (int q = 0; q < E; ++q) {
+        real sn, cs;
+        sincos_t(kca * phi[0][q], &sn, &cs);
+        va[q] = cmul(cscale(va[q], a.scale), mk<real>(cs, sn));
     }
+    LineFft<real, N, -1, true>::run(va, t.j0, t.line, tw);
+    if (act_a) a_store_T(va, t, lds, a.Xout, xa);
+    lds_barrier();
+
+    a_fetch_T(vb, t, a.X, xb);
+    a_cols_to_lines(vb, t, lds);
+    LineFft<real, N, +1, true>::run(vb, t.j0, t.line, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        real sn, cs;
+        sincos_t(kcb * phi[1][q], &sn, &cs);
+        vb[q] = cmul(cscale(vb[q], a.scale), mk<real>(cs, sn));
+    }
+    LineFft<real, N, -1, true>::run(vb, t.j0, t.line, tw);
+    if (act_b) a_store_T(vb, t, lds, a.Xout, xb);
 }
 
 // dst[z][y][x] = src[x][y][z] for one N^3 grid (psi_k downloads from the P[kx][ky][kz] layout)
@@ -1605,6 +1668,7 @@ int Engine::init(std::string& err) {
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
     if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
+    if (N_ == tp::N && sizeof(real) == 8 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
     const real L = (real)cfg_.axis_length;

@@ -110,11 +110,22 @@ template <int N, int AX> struct Geom {
 
 __device__ __forceinline__ int lds_pad(int p) { return p + (p >> 4); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load and store of the wave (s_waitcnt vmcnt(0)); the exchanges here communicate through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Exchange synchronisation.  When all threads of a line sit in one wavefront (LOCAL) the LDS
+// operations of the exchange are ordered by the wave's own instruction stream: no barrier at all.
+template <bool LOCAL> __device__ __forceinline__ void exch_sync() {
+    if constexpr (LOCAL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else lds_barrier();
+}
+
 // Runs all stages of one length-N transform on the E register values of this
 // thread.  `line` points at this line's padded LDS region, `tw` at the
-// LDS-resident table tw[p] = exp(-2 pi i p / N).  Contains __syncthreads():
-// every thread of the workgroup must call it.
-template <typename T, int N, int SGN>
+// LDS-resident table tw[p] = exp(-2 pi i p / N).  Unless LOCAL (a line's threads share a wavefront)
+// it contains workgroup barriers and every thread of the workgroup must call it; `tw` must be
+// visible to the caller's threads beforehand.
+template <typename T, int N, int SGN, bool LOCAL = false>
 struct LineFft {
     using P = Plan<N>;
     static constexpr int E = P::E, TPL = N / E;
@@ -150,10 +161,10 @@ struct LineFft {
             }
         }
         if constexpr (!LAST) {
-            __syncthreads();
+            exch_sync<LOCAL>();
 #pragma unroll
             for (int q = 0; q < E; ++q) v[q] = line[lds_pad(j0 + TPL * q)];
-            if constexpr (SIDX + 2 < P::S) __syncthreads();
+            if constexpr (SIDX + 2 < P::S) exch_sync<LOCAL>();
             stage<SIDX + 1, NS * R>(v, j0, line, tw);
         }
     }
@@ -166,7 +177,7 @@ struct LineFft {
 // The same transform for workgroups whose LDS budget holds only one REAL plane of the tile:
 // every exchange moves the real parts and then the imaginary parts through `line`
 // (LINE padded reals per line).  On return other threads may still be reading `line`.
-template <typename T, int N, int SGN>
+template <typename T, int N, int SGN, bool LOCAL = false>
 struct LineFftSplit {
     using P = Plan<N>;
     static constexpr int E = P::E, TPL = N / E;
@@ -202,18 +213,18 @@ struct LineFftSplit {
             for (int u = 0; u < BPT; ++u)
 #pragma unroll
                 for (int t = 0; t < R; ++t) line[lds_pad(o[u] + t * NS)] = v[u + t * BPT].x;
-            __syncthreads();
+            exch_sync<LOCAL>();
 #pragma unroll
             for (int q = 0; q < E; ++q) v[q].x = line[lds_pad(j0 + TPL * q)];
-            __syncthreads();
+            exch_sync<LOCAL>();
 #pragma unroll
             for (int u = 0; u < BPT; ++u)
 #pragma unroll
                 for (int t = 0; t < R; ++t) line[lds_pad(o[u] + t * NS)] = v[u + t * BPT].y;
-            __syncthreads();
+            exch_sync<LOCAL>();
 #pragma unroll
             for (int q = 0; q < E; ++q) v[q].y = line[lds_pad(j0 + TPL * q)];
-            if constexpr (SIDX + 2 < P::S) __syncthreads();
+            if constexpr (SIDX + 2 < P::S) exch_sync<LOCAL>();
             stage<SIDX + 1, NS * R>(v, j0, line, tw);
         }
     }

@@ -185,6 +185,64 @@ __global__ __launch_bounds__(512) void k_bhalf(double2* __restrict__ a, long run
         base[(size_t)(2 * chunk + half) * 4 + in] = v[q];
     }
 }
+// B half-runs when the 8-element block is [zl(2)][kx(4)] and a half owns kx bit 1: two 32-B pieces per block.
+template <int PART, int LDSB>
+__global__ __launch_bounds__(512) void k_bhalf32(double2* __restrict__ a, long runs) {
+    __shared__ char pad[LDSB > 0 ? LDSB : 1];
+    if (LDSB > 0 && threadIdx.x == 0 && runs < 0) pad[0] = 1;
+    const int tid = threadIdx.x;
+    const long g = blockIdx.x / (2 * PART);
+    const int r = blockIdx.x % (2 * PART), half = r / PART;
+    const long run = g * PART + r % PART;
+    if (run >= runs) return;
+    double2* base = a + (size_t)run * 16384;
+    double2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + 512 * q;               // 0..8191 within the half
+        const int blk = i >> 2, zl = (i >> 1) & 1, lo = i & 1;
+        v[q] = base[(size_t)blk * 8 + zl * 4 + half * 2 + lo];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + 512 * q;
+        const int blk = i >> 2, zl = (i >> 1) & 1, lo = i & 1;
+        v[q].x += 1.0;
+        base[(size_t)blk * 8 + zl * 4 + half * 2 + lo] = v[q];
+    }
+}
+// A side with 4096-element tiles (one zl, 256 threads): 64-B chunks [kx(4)] of the block, partner (other zl) PART blocks away.
+template <int DIR, int PART, int LDSB>
+__global__ __launch_bounds__(256) void k_aseg64(double2* __restrict__ t, double2* __restrict__ x, long tiles, long st, long sk,
+                                                long sz, long sb) {
+    __shared__ char pad[LDSB > 0 ? LDSB : 1];
+    if (LDSB > 0 && threadIdx.x == 0 && tiles < 0) pad[0] = 1;
+    const int tid = threadIdx.x;
+    const long g = blockIdx.x / (2 * PART);
+    const int r = blockIdx.x % (2 * PART), zl = r / PART;
+    const long w = g * PART + r % PART;           // (stream, zh, b)
+    const size_t off = (size_t)(w / 2048) * N * N * N;
+    const int tile = (int)(w % 2048), zh = tile / 16, b = tile % 16;
+    double2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + 256 * q;               // (tp, kxh, in4)
+        const int in = i & 3, kxh = (i >> 2) & 63, tp = i >> 8;
+        const size_t it = (size_t)tp * st + (size_t)kxh * sk + (size_t)zh * sz + (size_t)b * sb + zl * 4 + in;
+        const int xx = i & 255, row = i >> 8;
+        const size_t ix = ((size_t)(zh * 2 + zl) * 256 + (b + 16 * row)) * 256 + xx;
+        v[q] = DIR == 0 ? t[off + it] : x[off + ix];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + 256 * q;
+        const int in = i & 3, kxh = (i >> 2) & 63, tp = i >> 8;
+        const size_t it = (size_t)tp * st + (size_t)kxh * sk + (size_t)zh * sz + (size_t)b * sb + zl * 4 + in;
+        const int xx = i & 255, row = i >> 8;
+        const size_t ix = ((size_t)(zh * 2 + zl) * 256 + (b + 16 * row)) * 256 + xx;
+        if (DIR == 0) x[off + ix] = v[q]; else t[off + it] = v[q];
+    }
+}
 // A side: 8192-element tile = 1024 segments of 8 elements (128 B); segment (tp, kxh) at
 // tp*st + kxh*sk + tilebase; other side 32 natural rows of 4 KiB.  DIR 0: T -> rows, 1: rows -> T.
 template <int DIR, int LDSB>
@@ -281,6 +339,16 @@ int main(int argc, char** argv) {
             printf("B half-tiles (64-B chunks), partner +8, 2 WG/CU: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
             ms = timeit([&] { k_bhalf<16, 73984><<<2 * runs, 512>>>(a, runs); });
             printf("B half-tiles (64-B chunks), partner +16, 2 WG/CU: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+            ms = timeit([&] { k_bhalf32<8, 73984><<<2 * runs, 512>>>(a, runs); });
+            printf("B half-tiles (2x32-B pieces), partner +8, 2 WG/CU: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+            {
+                const long tl2 = 2 * 2048L * streams;
+                const long st = 64L * 128 * 16 * 8, sk = 128L * 16 * 8, sz = 16 * 8, sb = 8;
+                ms = timeit([&] { k_aseg64<0, 8, 73984><<<tl2, 256>>>(a, b, tl2, st, sk, sz, sb); });
+                printf("A 4K tile (64-B chunks, partner +8), T -> rows: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_aseg64<1, 8, 73984><<<tl2, 256>>>(a, b, tl2, st, sk, sz, sb); });
+                printf("A 4K tile (64-B chunks, partner +8), rows -> T: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+            }
             const long tl = 2048L * streams;
             struct L { const char* name; long st, sk, sz, sb; } ls[] = {
                 {"[tp][kxh][zh][b]  (B contiguous)", 64L * 128 * 16 * 8, 128L * 16 * 8, 16 * 8, 8},
