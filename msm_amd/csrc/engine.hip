@@ -1542,7 +1542,7 @@ class Engine final : public IEngine {
     void derived(double out[8]) const override {
         out[0] = (double)dx_; out[1] = (double)dx_; out[2] = (double)c_.k2max; out[3] = (double)c_.hbar;
         out[4] = cfg_.total_mass / cfg_.particle_mass;
-        out[5] = (double)kinetic_dt_; out[6] = (double)comoving_box_; out[7] = 0.0;
+        out[5] = (double)kinetic_dt_; out[6] = (double)comoving_box_; out[7] = psi2_ ? 2.0 : (two_pass_ ? 1.0 : 0.0);
     }
     int batch() const override { return batch_; }
 

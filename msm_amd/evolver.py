@@ -103,8 +103,8 @@ class Evolver:
     def derived(self) -> dict:
         out = (C.c_double * 8)()
         self._check(self._lib.msm_get_derived(self._ctx, out), "msm_get_derived")
-        keys = ["dx", "dk", "k2_max", "hbar_", "n_tot", "kinetic_dt", "comoving_boxsize"]
-        return dict(zip(keys, list(out)[:7]))
+        keys = ["dx", "dk", "k2_max", "hbar_", "n_tot", "kinetic_dt", "comoving_boxsize", "transform_passes_mode"]
+        return dict(zip(keys, list(out)))
 
     # -- initial conditions ----------------------------------------------
     def set_psi(self, stream: int, psi: np.ndarray):

@@ -370,6 +370,58 @@ def test_steps_and_potential_256_vs_cpu_port():
         sim.close()
 
 
+def _run_mode_256(mode, cosmology=None):
+    """Five streams in sub-batches of four (one unpaired), stream 1 carrying grid-scale noise so that
+    it aliases on the first step and sits out the rest; returns status rows and fields."""
+    N = 256
+    os.environ["MSM_TWO_PASS"] = str(mode)
+    try:
+        base = dict(TOPHAT, cfl=0.05, alias_threshold=1e-4, k2_cutoff=0.5)
+        with Evolver(size=N, n_streams=5, batch_streams=4, cosmology=cosmology, **base) as ev:
+            for s in range(5):
+                psi = rand_psi(N, 20 + s) * (0.5 if s == 1 else 1e-3) + 1.0
+                ev.set_psi(s, o.normalize(psi, 30.0 / N, 3))
+            rows = []
+            for i in range(3):
+                if cosmology:
+                    ev.step_begin([0.5] * 5, [1e9] * 5)
+                    st = ev.status()
+                    ev.step_end([0.5] * 5, [st[s].time + st[s].dt for s in range(5)],
+                                [st[s].tau + st[s].dt for s in range(5)], [0.0] * 5)
+                else:
+                    ev.update()
+                rows.append([(r.dt, r.time, r.max_phi, r.alias_mass, r.active, r.aliased, r.n_steps) for r in ev.status()])
+            psi = [ev.get_psi(s) for s in range(5)]
+            psik = [ev.get_psik(s) for s in range(5)]
+            ev.calculate_potential(0, 4)
+            phi = [ev.get_potential(s) for s in range(4)]
+        return rows, psi, psik, phi
+    finally:
+        os.environ.pop("MSM_TWO_PASS", None)
+
+
+@pytest.mark.parametrize("cosmology", [None, dict(omega_matter_now=1.0, omega_radiation_now=0.0, h=0.7, z0=9.0, max_dloga=0.01)],
+                         ids=["static", "expanding"])
+def test_two_pass_engine_matches_three_pass_256(cosmology):
+    """The 256^3 two-pass engine (blocked work-array layouts, psi_k kept transposed) against the
+    plain three-passes-per-transform engine that the small-N oracle tests pin: same steps, same
+    activity flags, fields equal to rounding -- with an unpaired stream and a stream that drops out."""
+    r3, psi3, psik3, phi3 = _run_mode_256(0, cosmology)
+    r2, psi2, psik2, phi2 = _run_mode_256(2, cosmology)
+    assert [row[1][4] for row in r3] == [0, 0, 0] and r3[0][1][5] == 1       # stream 1 aliased at step 1
+    for a, b in zip(r3, r2):
+        for x, y in zip(a, b):
+            assert x[4:] == y[4:]
+            assert abs(x[0] / y[0] - 1) < 1e-12 and abs(x[1] / y[1] - 1) < 1e-12
+            assert abs(x[2] / y[2] - 1) < 1e-11
+            assert abs(x[3] - y[3]) <= 1e-9 * max(abs(x[3]), 1e-30) + 1e-22
+    for s in range(5):
+        assert rel_err(psi2[s], psi3[s]) < 1e-11
+        assert rel_err(psik2[s], psik3[s]) < 1e-11
+    for s in range(4):
+        assert rel_err(phi2[s], phi3[s]) < 1e-11
+
+
 _DENSITY_SCRIPT = r"""
 import sys
 import numpy as np
