@@ -244,7 +244,7 @@ template <int N, int AX>
 __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
     using G = Geom<N, AX>;
     if constexpr (G::USES_LDS) {
-        for (int i = threadIdx.x; i < N; i += G::THREADS) tw_lds[i] = tw_g[i];
+        for (int i = threadIdx.x; i < N; i += G::THREADS) tw_lds[i] = tw_g[TwLayout<N>::source(i)];
         // visibility: x lines exchange inside their wavefront, so the table needs its own barrier;
         // on the strided axes the first use is after the stage-0 exchange barrier
         if constexpr (AX == 0) lds_barrier();
@@ -700,8 +700,15 @@ constexpr int A_HALF = 16 * A_LINE + 8;            // zl = 1 lines start 128 B o
 constexpr int A_LDS = 2 * A_HALF + N;              // + twiddle table
 constexpr int A_TILES = 2048;                      // zh (128) x b (16)
 constexpr size_t T_TP = (size_t)64 * 16384;        // stride of t' in T
-constexpr int B_THREADS = 512, B_LINE = 272;       // reals per padded z line; 272 = 16 mod 32 keeps line pairs on disjoint banks
-constexpr int B_BLOCKS = 2 * 1024;                 // two half-runs per (t', kx >> 2)
+#ifndef MSM_B_FULL
+#define MSM_B_FULL 1
+#endif
+constexpr bool B_FULL = MSM_B_FULL != 0;           // one 1024-thread workgroup per run instead of two of 512 per half-run
+constexpr int B_THREADS = B_FULL ? 1024 : 512;
+constexpr int B_LINE = 272;                        // reals per padded z line; 272 = 16 mod 32 keeps line pairs on disjoint banks
+constexpr int B_LINES = B_FULL ? 64 : 32;          // z lines per workgroup: 16 b' x the kx it owns
+constexpr int B_PLANE = B_LINES * B_LINE + 8;
+constexpr int B_BLOCKS = B_FULL ? 1024 : 2 * 1024; // (half-)runs per grid: (t', kx >> 2) [x kx bit 1]
 constexpr int MAX_BATCH = 256;                     // streams per sub-batch the A kernels keep flags for
 }
 
@@ -770,7 +777,7 @@ __device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* ld
 }
 
 __device__ __forceinline__ void a_load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
-    if (threadIdx.x < tp::N) tw_lds[threadIdx.x] = tw_g[threadIdx.x];
+    if (threadIdx.x < tp::N) tw_lds[threadIdx.x] = tw_g[TwLayout<tp::N>::source(threadIdx.x)];
     lds_barrier();
 }
 
@@ -958,14 +965,24 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
 //   column role: thread = (z = tid >> 1, kx bit 0 = tid & 1), holds the 16 values b (or b')
 //   line role:   thread = (j0 = tid & 15, line L = tid >> 4 = 2 b' + kx bit 0), holds z = j0 + 16 q
 struct RolesB {
-    int j0, L;
+    int j0, L, bprime, kxl;   // line role: z = j0 + 16 q of line L = (b', kx low bits kxl)
     real* colw;
     real* line;
+    // Lines are stored as L = (kx bit 1) * 32 + 2 b' + (kx bit 0); the upper half of a full run's lines is
+    // skewed by 8 reals so that the four kx of a column access fall on distinct bank quarters.
+    static __device__ __forceinline__ int line_off(int L) { return L * tp::B_LINE + (L >> 5) * 8; }
     __device__ __forceinline__ RolesB(real* plane) {
         const int tid = threadIdx.x;
         j0 = tid & 15; L = tid >> 4;
-        colw = plane + (tid & 1) * tp::B_LINE + lds_pad(tid >> 1);
-        line = plane + L * tp::B_LINE;
+        line = plane + line_off(L);
+        bprime = (L >> 1) & 15; kxl = ((L >> 5) << 1) | (L & 1);
+        if constexpr (tp::B_FULL) {
+            // column role: the lane's position in the 8-element block is (kx bit 1, zl, kx bit 0)
+            const int inner = tid & 7, z = 2 * (tid >> 3) + ((inner >> 1) & 1);
+            colw = plane + line_off((inner >> 2) * 32 + (inner & 1)) + lds_pad(z);
+        } else {
+            colw = plane + (tid & 1) * tp::B_LINE + lds_pad(tid >> 1);
+        }
     }
 };
 // column -> line; the plane must be free on entry and is free again on return
@@ -1001,11 +1018,17 @@ __device__ __forceinline__ void b_to_cols(cplx (&v)[16], const RolesB& r) {
 // blockIdx.x -> (half-run, run): partner half-runs sit 8 blocks apart
 struct RunB {
     int half, run, tpi, kxh;
+    size_t off;       // first element of this workgroup's (half-)run within a grid
+    unsigned toff;    // this lane's element within it (column role)
     __device__ __forceinline__ RunB() {
-        const int bx = blockIdx.x;
-        half = (bx >> 3) & 1; run = ((bx >> 4) << 3) | (bx & 7);
+        const int bx = blockIdx.x, tid = threadIdx.x;
+        if constexpr (tp::B_FULL) { half = 0; run = bx; toff = (unsigned)tid; }
+        else { half = (bx >> 3) & 1; run = ((bx >> 4) << 3) | (bx & 7); toff = (unsigned)((tid >> 2) * 8 + (tid & 3)); }
         tpi = run >> 6; kxh = run & 63;      // t', kx >> 2
+        off = (size_t)run * 16384 + half * 4;
     }
+    __device__ __forceinline__ int kx(const RolesB& r) const { return (kxh << 2) | (half << 1) | r.kxl; }
+    __device__ __forceinline__ int ky(const RolesB& r) const { return tpi + 16 * r.bprime; }
 };
 // T (column role) -> inner y stage -> line role -> z transform; v ends as kz = j0 + 16 q
 __device__ __forceinline__ void b_forward(cplx (&v)[16], const cplx* __restrict__ T, size_t trun, unsigned toff,
@@ -1036,21 +1059,21 @@ __device__ __forceinline__ void b_inverse(cplx (&v)[16], cplx* __restrict__ T, s
 // simulation_object.rs:1076-1102), and both stages back, on one half-run of T in place.
 __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_poisson_b(PoisArgs a) {
     constexpr int N = tp::N;
-    __shared__ real plane[32 * tp::B_LINE];
+    __shared__ real plane[tp::B_PLANE];
     __shared__ cplx tw[N];
     const int tid = threadIdx.x;
     const int p = blockIdx.y;
     const int sa = a.s0 + 2 * p, sb = sa + 1;
     if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
-    if (tid < N) tw[tid] = a.tw[tid];   // first read is behind the exchange barriers
+    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];   // first read is behind the exchange barriers
     const RunB rb;
     const RolesB r(plane);
-    const size_t trun = (size_t)p * a.n3 + (size_t)rb.run * 16384 + rb.half * 4;
-    const unsigned toff = (unsigned)((tid >> 2) * 8 + (tid & 3));
+    const size_t trun = (size_t)p * a.n3 + rb.off;
+    const unsigned toff = rb.toff;
 
     cplx v[16];
     b_forward(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
-    const int kx = (rb.kxh << 2) | (rb.half << 1) | (r.L & 1), ky = rb.tpi + 16 * (r.L >> 1);
+    const int kx = rb.kx(r), ky = rb.ky(r);
     const real kxy = a.ksq[kx] + a.ksq[ky];   // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1085,18 +1108,18 @@ enum { PB_FWD = 0, PB_INV = 1, PB_MID = 2 };
 template <int MODE, int DRIFT>
 __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_b(PsiBArgs a) {
     constexpr int N = tp::N;
-    __shared__ real plane[32 * tp::B_LINE];
+    __shared__ real plane[tp::B_PLANE];
     __shared__ cplx tw[N];
-    __shared__ double red[MODE == PB_MID ? 8 : 1];
+    __shared__ double red[MODE == PB_MID ? tp::B_THREADS / 64 : 1];
     const int tid = threadIdx.x;
     const int ls = blockIdx.y, sg = a.s0 + ls;
     if (a.active != nullptr && !a.active[sg]) return;
-    if (tid < N) tw[tid] = a.tw[tid];
+    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];
     const RunB rb;
     const RolesB r(plane);
-    const size_t trun = (size_t)ls * a.n3 + (size_t)rb.run * 16384 + rb.half * 4;
-    const unsigned toff = (unsigned)((tid >> 2) * 8 + (tid & 3));
-    const int kx = (rb.kxh << 2) | (rb.half << 1) | (r.L & 1), ky = rb.tpi + 16 * (r.L >> 1);
+    const size_t trun = (size_t)ls * a.n3 + rb.off;
+    const unsigned toff = rb.toff;
+    const int kx = rb.kx(r), ky = rb.ky(r);
     cplx* __restrict__ prow = a.P + (size_t)sg * a.n3 + ((size_t)kx * N + ky) * N + r.j0;
     const cplx* __restrict__ d = a.drift + (size_t)sg * N;
 
@@ -1128,7 +1151,7 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
             if (tid == 0) {
                 double tot = red[0];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) tot += red[w];
+                for (int w = 1; w < tp::B_THREADS / 64; ++w) tot += red[w];
                 a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
             }
         }

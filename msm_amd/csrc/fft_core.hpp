@@ -85,6 +85,17 @@ template <> struct Plan<32>   { static constexpr int E = 16, S = 2, R0 = 16, R1 
 template <> struct Plan<64>   { static constexpr int E = 16, S = 2, R0 = 16, R1 = 4,  R2 = 1; };
 template <> struct Plan<128>  { static constexpr int E = 16, S = 2, R0 = 16, R1 = 8,  R2 = 1; };
 template <> struct Plan<256>  { static constexpr int E = 16, S = 2, R0 = 16, R1 = 16, R2 = 1; };
+// LDS twiddle-table addressing.  Entry for butterfly phase index k (0..NS-1) and leg t is
+// exp(-2 pi i k t TWS / N).  The natural table tw[k t TWS] makes the lanes of one read (fixed t,
+// k = lane) stride by t elements -- multi-way bank conflicts for t = 4, 8, 12.  For N = 256 only the
+// second stage has twiddles (k < 16, t < 16), so its table is stored leg-major, tw[16 t + k], and
+// one read touches 16 consecutive entries.
+template <int N> struct TwLayout {
+    static constexpr bool LEG_MAJOR = (N == 256);
+    static __device__ __forceinline__ int index(int k, int t, int tws) { return LEG_MAJOR ? (t * 16 + k) : (k * t * tws); }
+    // table slot i holds the natural entry source(i)
+    static __device__ __forceinline__ int source(int i) { return LEG_MAJOR ? (((i & 15) * (i >> 4)) & (N - 1)) : i; }
+};
 template <> struct Plan<512>  { static constexpr int E = 16, S = 3, R0 = 16, R1 = 16, R2 = 2; };
 
 // Lines per workgroup: MSM_LPW_X for passes along the contiguous axis, MSM_LPW_S for the
@@ -146,7 +157,7 @@ struct LineFft {
                 constexpr int TWS = N / (NS * R);
 #pragma unroll
                 for (int t = 1; t < R; ++t) {
-                    const cx<T> w = tw[k * t * TWS];
+                    const cx<T> w = tw[TwLayout<N>::index(k, t, TWS)];
                     a[t] = (SGN < 0) ? cmul(a[t], w) : cmulc(a[t], w);
                 }
             }
@@ -199,7 +210,7 @@ struct LineFftSplit {
                 constexpr int TWS = N / (NS * R);
 #pragma unroll
                 for (int t = 1; t < R; ++t) {
-                    const cx<T> w = tw[k * t * TWS];
+                    const cx<T> w = tw[TwLayout<N>::index(k, t, TWS)];
                     a[t] = (SGN < 0) ? cmul(a[t], w) : cmulc(a[t], w);
                 }
             }
