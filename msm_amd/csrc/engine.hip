@@ -688,10 +688,13 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
 // so the pair-packed work array crosses HBM twice per solve instead of four times.
 // With y = b + 16 t, ky = t' + 16 b':  F_y = DFT16_b[ w^(b t') DFT16_t[.] ],  w = e^(-2 pi i / 256).
 // An A tile is 32 x-lines: 16 rows y = b + 16 t of the two planes z = 2 zh + zl.  Between the passes
-// W is stored as  T[t'][kx >> 2][b][zh][kx bit 1][zl][kx bit 0] : 128-byte blocks for the A tiles,
-// one contiguous 256-KiB run per (t', kx >> 2) for pass B, whose two 512-thread workgroups (kx bit 1
-// = 0 / 1) take alternate 64-byte chunks of the run and are placed 8 blocks apart so that they
-// share an L2.
+// a grid is stored as
+//     T[t'][kx >> 4][b][zh][(kx >> 2) & 3][kx bit 1][zl][kx bit 0]
+// The innermost 8 elements (128 B) are what an A tile and a B run have in common.  Four such blocks
+// with neighbouring kx sit side by side: an A tile (fixed b, zh; all t', kx) moves 512-byte pieces,
+// a B run (fixed t', kx >> 2; all b, z) moves 128-byte pieces 512 B apart whose neighbours belong to
+// the next three runs, i.e. to workgroups in flight at the same time.  Measured as plain copies this
+// split serves both sides at 5.0 / 5.7 TB/s; fully contiguous B runs left the A side at 3.8 TB/s.
 // ---------------------------------------------------------------------------
 namespace tp {
 constexpr int N = 256;
@@ -699,16 +702,14 @@ constexpr int A_THREADS = 512, A_LINE = Geom<N, 0>::LINE_LDS;
 constexpr int A_HALF = 16 * A_LINE + 8;            // zl = 1 lines start 128 B off the bank period of zl = 0
 constexpr int A_LDS = 2 * A_HALF + N;              // + twiddle table
 constexpr int A_TILES = 2048;                      // zh (128) x b (16)
-constexpr size_t T_TP = (size_t)64 * 16384;        // stride of t' in T
-#ifndef MSM_B_FULL
-#define MSM_B_FULL 1
-#endif
-constexpr bool B_FULL = MSM_B_FULL != 0;           // one 1024-thread workgroup per run instead of two of 512 per half-run
-constexpr int B_THREADS = B_FULL ? 1024 : 512;
+constexpr size_t T_TP = (size_t)64 * 16384;        // stride of t' in T (elements)
+constexpr int B_THREADS = 1024;                    // one workgroup per run (t', kx >> 2): 16 b x 256 z x 4 kx
 constexpr int B_LINE = 272;                        // reals per padded z line; 272 = 16 mod 32 keeps line pairs on disjoint banks
-constexpr int B_LINES = B_FULL ? 64 : 32;          // z lines per workgroup: 16 b' x the kx it owns
+constexpr int B_LINES = 64;                        // z lines per workgroup: 16 b' x 4 kx
 constexpr int B_PLANE = B_LINES * B_LINE + 8;
-constexpr int B_BLOCKS = B_FULL ? 1024 : 2 * 1024; // (half-)runs per grid: (t', kx >> 2) [x kx bit 1]
+constexpr int B_BLOCKS = 1024;                     // runs per grid
+constexpr int KL = 4;                              // 128-byte blocks of neighbouring kx side by side in T
+constexpr size_t T_B = (size_t)128 * KL * 8;       // stride of b in T (elements)
 constexpr int MAX_BATCH = 256;                     // streams per sub-batch the A kernels keep flags for
 }
 
@@ -738,7 +739,7 @@ __device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* l
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = col[q * tp::A_LINE];
     dft<16, -1, real>(v);
-    const unsigned off = (unsigned)((kxh * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7));
+    const unsigned off = (unsigned)(((((kxh >> 2) * 16 + t.b) * 128 + t.zh) * 4 + (kxh & 3)) * 8 + (tid & 7));
 #pragma unroll
     for (int q = 0; q < 16; ++q) (wT + (grid_off + (size_t)q * tp::T_TP))[off] = v[q];
 }
@@ -751,7 +752,8 @@ typedef real real2v __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) real2v* gcptr;
 __device__ __forceinline__ void a_fetch_T(cplx (&v)[16], const TileA& t, const cplx* __restrict__ wT, size_t grid_off) {
     const int tid = threadIdx.x;
-    gcptr p = (gcptr)(wT + grid_off + (size_t)(((tid >> 3) * 16 + t.b) * 1024 + t.zh * 8 + (tid & 7)));
+    const int kxh = tid >> 3;
+    gcptr p = (gcptr)(wT + grid_off + (size_t)(((((kxh >> 2) * 16 + t.b) * 128 + t.zh) * 4 + (kxh & 3)) * 8 + (tid & 7)));
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const real2v d = *p;
@@ -968,21 +970,17 @@ struct RolesB {
     int j0, L, bprime, kxl;   // line role: z = j0 + 16 q of line L = (b', kx low bits kxl)
     real* colw;
     real* line;
-    // Lines are stored as L = (kx bit 1) * 32 + 2 b' + (kx bit 0); the upper half of a full run's lines is
-    // skewed by 8 reals so that the four kx of a column access fall on distinct bank quarters.
+    // Lines are stored as L = (kx bit 1) * 32 + 2 b' + (kx bit 0); the upper half is skewed by 8 reals
+    // so that the four kx of a column access fall on distinct bank quarters.
     static __device__ __forceinline__ int line_off(int L) { return L * tp::B_LINE + (L >> 5) * 8; }
     __device__ __forceinline__ RolesB(real* plane) {
         const int tid = threadIdx.x;
         j0 = tid & 15; L = tid >> 4;
         line = plane + line_off(L);
         bprime = (L >> 1) & 15; kxl = ((L >> 5) << 1) | (L & 1);
-        if constexpr (tp::B_FULL) {
-            // column role: the lane's position in the 8-element block is (kx bit 1, zl, kx bit 0)
-            const int inner = tid & 7, z = 2 * (tid >> 3) + ((inner >> 1) & 1);
-            colw = plane + line_off((inner >> 2) * 32 + (inner & 1)) + lds_pad(z);
-        } else {
-            colw = plane + (tid & 1) * tp::B_LINE + lds_pad(tid >> 1);
-        }
+        // column role: the lane's position in the 8-element block is (kx bit 1, zl, kx bit 0), zh = tid >> 3
+        const int inner = tid & 7, z = 2 * (tid >> 3) + ((inner >> 1) & 1);
+        colw = plane + line_off((inner >> 2) * 32 + (inner & 1)) + lds_pad(z);
     }
 };
 // column -> line; the plane must be free on entry and is free again on return
@@ -1015,19 +1013,18 @@ __device__ __forceinline__ void b_to_cols(cplx (&v)[16], const RolesB& r) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q].y = r.colw[q * CS];
 }
-// blockIdx.x -> (half-run, run): partner half-runs sit 8 blocks apart
+// blockIdx.x = run = (t', kx >> 2); neighbouring runs interleave in memory and run side by side
 struct RunB {
-    int half, run, tpi, kxh;
-    size_t off;       // first element of this workgroup's (half-)run within a grid
-    unsigned toff;    // this lane's element within it (column role)
+    int run, tpi, kxh;
+    size_t off;       // first element of this run within a grid
+    unsigned toff;    // this lane's element within it (column role): (zh, position in the block)
     __device__ __forceinline__ RunB() {
-        const int bx = blockIdx.x, tid = threadIdx.x;
-        if constexpr (tp::B_FULL) { half = 0; run = bx; toff = (unsigned)tid; }
-        else { half = (bx >> 3) & 1; run = ((bx >> 4) << 3) | (bx & 7); toff = (unsigned)((tid >> 2) * 8 + (tid & 3)); }
-        tpi = run >> 6; kxh = run & 63;      // t', kx >> 2
-        off = (size_t)run * 16384 + half * 4;
+        const int tid = threadIdx.x;
+        run = blockIdx.x; tpi = run >> 6; kxh = run & 63;
+        off = (size_t)(tpi * 16 + (kxh >> 2)) * 16 * tp::T_B + (kxh & 3) * 8;
+        toff = (unsigned)((tid >> 3) * (tp::KL * 8) + (tid & 7));
     }
-    __device__ __forceinline__ int kx(const RolesB& r) const { return (kxh << 2) | (half << 1) | r.kxl; }
+    __device__ __forceinline__ int kx(const RolesB& r) const { return (kxh << 2) | r.kxl; }
     __device__ __forceinline__ int ky(const RolesB& r) const { return tpi + 16 * r.bprime; }
 };
 // T (column role) -> inner y stage -> line role -> z transform; v ends as kz = j0 + 16 q
@@ -1035,7 +1032,7 @@ __device__ __forceinline__ void b_forward(cplx (&v)[16], const cplx* __restrict_
                                           int tpi, const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
     const bufdesc rs = buf_of(T + trun);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) buf_ld(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * 1024 * sizeof(cplx)));
+    for (int q = 0; q < 16; ++q) buf_ld(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * tp::T_B * sizeof(cplx)));
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
     dft<16, -1, real>(v);
@@ -1052,11 +1049,11 @@ __device__ __forceinline__ void b_inverse(cplx (&v)[16], cplx* __restrict__ T, s
     for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
     const bufdesc rs = buf_of(T + trun);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) buf_st(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * 1024 * sizeof(cplx)));
+    for (int q = 0; q < 16; ++q) buf_st(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * tp::T_B * sizeof(cplx)));
 }
 
 // Pass B of the Poisson solve: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
-// simulation_object.rs:1076-1102), and both stages back, on one half-run of T in place.
+// simulation_object.rs:1076-1102), and both stages back, on one run of T in place.
 __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_poisson_b(PoisArgs a) {
     constexpr int N = tp::N;
     __shared__ real plane[tp::B_PLANE];
@@ -1219,7 +1216,7 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho3(PoisArgs a) {
     const int pairs = (a.nb + 1) / 2, last = a.nb - 1;
     cplx va[E], vb[E];
     a_fetch_T(va, t, a.X, 0);
-    for (int p = 0; p < pairs; ++p) {
+    auto pair_body = [&](int p) {
         const bool act_a = act_lds[2 * p] != 0, act_b = act_lds[2 * p + 1] != 0;   // uniform over the workgroup
         a_fetch_T(vb, t, a.X, (size_t)min(2 * p + 1, last) * a.n3);
         real rho0[E];
@@ -1247,7 +1244,10 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho3(PoisArgs a) {
         LineFft<real, N, -1, true>::run(vb, t.j0, t.line, tw);
         a_store_T(vb, t, lds, a.W, (size_t)p * a.n3);   // a pair of finished streams stores zeros
         lds_barrier();
-    }
+    };
+    // first pair peeled: the loop is then entered with the same loads and stores in flight as its back edge leaves
+    pair_body(0);
+    for (int p = 1; p < pairs; ++p) pair_body(p);
     if constexpr (DENS) {
 #pragma unroll
         for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];

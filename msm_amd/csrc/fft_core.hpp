@@ -113,7 +113,11 @@ template <int N, int AX> struct Geom {
     static constexpr int LPW0 = AX == 0 ? MSM_LPW_X : MSM_LPW_S;
     static constexpr int LPW = N < LPW0 ? N : LPW0;    // lines per workgroup
     static constexpr int THREADS = TPL * LPW;
-    static constexpr int LINE_LDS = N + (N >> 4) + 1;  // padded line length in LDS (elements)
+    // Padded line length in LDS (elements of 16 B in double).  On the strided axes the 16 lanes of a
+    // ds_read_b128 group are 16 neighbouring lines at one position: an odd stride spreads them over
+    // the 16 slots of the 256-byte bank row.  Along x a group is one line's lanes 0-3,12-15 and the
+    // next line's lanes 4-11 (or the complement): a stride that is a multiple of 16 keeps them apart.
+    static constexpr int LINE_LDS = AX == 0 ? ((N + (N >> 4) + 15) & ~15) : (N + (N >> 4) + 1);
     static constexpr bool USES_LDS = P::S > 1;
     // LDS elements: LPW padded lines + the N-entry twiddle table.
     static constexpr int LDS_ELEMS = USES_LDS ? (LPW * LINE_LDS + N) : 1;

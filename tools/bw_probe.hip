@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512) void k_aseg(double2* __restrict__ t, double2* 
         const size_t it = (size_t)tp * st + (size_t)kxh * sk + (size_t)zh * sz + (size_t)b * sb + in;
         const int xx = i & 255, row = (i >> 8) & 15, zl = i >> 12;
         const size_t ix = ((size_t)(zh * 2 + zl) * 256 + (b + 16 * row)) * 256 + xx;
-        v[q] = DIR == 0 ? t[off + it] : x[off + ix];
+        v[q] = (DIR == 0 || DIR == 2) ? t[off + it] : x[off + ix];
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -271,7 +271,58 @@ __global__ __launch_bounds__(512) void k_aseg(double2* __restrict__ t, double2* 
         const size_t it = (size_t)tp * st + (size_t)kxh * sk + (size_t)zh * sz + (size_t)b * sb + in;
         const int xx = i & 255, row = (i >> 8) & 15, zl = i >> 12;
         const size_t ix = ((size_t)(zh * 2 + zl) * 256 + (b + 16 * row)) * 256 + xx;
-        if (DIR == 0) x[off + ix] = v[q]; else t[off + it] = v[q];
+        if (DIR == 0) x[off + ix] = v[q]; else if (DIR == 1) t[off + it] = v[q]; else x[off + it] = v[q];
+    }
+}
+
+// T layouts with KL neighbouring kx-groups interleaved below (b, zh):
+//   T[tp][kxh / KL][b][zh][kxh % KL][8]
+// A tile (fixed b, zh): pieces of KL*128 B; B run (fixed tp, kxh): 128-B pieces at stride KL*128 B.
+template <int KL, int DIR>
+__global__ __launch_bounds__(512) void k_aseg_kl(double2* __restrict__ t, double2* __restrict__ x, long tiles) {
+    __shared__ char pad[140000];
+    if (threadIdx.x == 0 && tiles < 0) pad[0] = 1;
+    const int tid = threadIdx.x;
+    const long w = blockIdx.x;
+    const size_t off = (size_t)(w / 2048) * N * N * N;
+    const int tile = (int)(w % 2048), zh = tile / 16, b = tile % 16;
+    double2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + 512 * q;               // (tp, kxh, in8)
+        const int in = i & 7, kxh = (i >> 3) & 63, tp = i >> 9;
+        const size_t it = ((((size_t)(tp * (64 / KL) + kxh / KL) * 16 + b) * 128 + zh) * KL + kxh % KL) * 8 + in;
+        v[q] = t[off + it];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + 512 * q;
+        const int in = i & 7, kxh = (i >> 3) & 63, tp = i >> 9;
+        const size_t it = ((((size_t)(tp * (64 / KL) + kxh / KL) * 16 + b) * 128 + zh) * KL + kxh % KL) * 8 + in;
+        x[off + it] = v[q];
+    }
+}
+template <int KL>
+__global__ __launch_bounds__(1024) void k_brun_kl(double2* __restrict__ a, long runs) {
+    __shared__ char pad[140000];
+    if (threadIdx.x == 0 && runs < 0) pad[0] = 1;
+    const int tid = threadIdx.x;
+    const long w = blockIdx.x;
+    const size_t off = (size_t)(w / 1024) * N * N * N;
+    const int run = (int)(w % 1024), tp = run >> 6, kxh = run & 63;
+    double2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                 // q = b; lane = (zh, in8)
+        const int zh = tid >> 3, in = tid & 7;
+        const size_t it = ((((size_t)(tp * (64 / KL) + kxh / KL) * 16 + q) * 128 + zh) * KL + kxh % KL) * 8 + in;
+        v[q] = a[off + it];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int zh = tid >> 3, in = tid & 7;
+        const size_t it = ((((size_t)(tp * (64 / KL) + kxh / KL) * 16 + q) * 128 + zh) * KL + kxh % KL) * 8 + in;
+        v[q].x += 1.0;
+        a[off + it] = v[q];
     }
 }
 
@@ -356,6 +407,36 @@ int main(int argc, char** argv) {
                 {"[tp][zh][b][kxh]  (A contiguous)", 128L * 16 * 64 * 8, 8, 16L * 64 * 8, 64 * 8},
                 {"[zh][b][tp][kxh]  (A tile contiguous)", 64 * 8, 8, 16L * 16 * 64 * 8, 16L * 64 * 8},
             };
+            {
+                auto& l = ls[0];
+                ms = timeit([&] { k_aseg<2, 73984><<<tl, 512>>>(a, b, tl, l.st, l.sk, l.sz, l.sb); });
+                printf("A 8K tile, T -> T (both 128-B segments), 2 WG/CU: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_aseg<2, 140000><<<tl, 512>>>(a, b, tl, l.st, l.sk, l.sz, l.sb); });
+                printf("A 8K tile, T -> T (both 128-B segments), 1 WG/CU: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+            }
+            {
+                const long tb2 = 1024L * streams;
+                ms = timeit([&] { k_aseg_kl<1, 0><<<tl, 512>>>(a, b, tl); });
+                printf("KL=1  A T->T : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_brun_kl<1><<<tb2, 1024>>>(a, tb2); });
+                printf("KL=1  B run  : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_aseg_kl<2, 0><<<tl, 512>>>(a, b, tl); });
+                printf("KL=2  A T->T : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_brun_kl<2><<<tb2, 1024>>>(a, tb2); });
+                printf("KL=2  B run  : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_aseg_kl<4, 0><<<tl, 512>>>(a, b, tl); });
+                printf("KL=4  A T->T : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_brun_kl<4><<<tb2, 1024>>>(a, tb2); });
+                printf("KL=4  B run  : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_aseg_kl<8, 0><<<tl, 512>>>(a, b, tl); });
+                printf("KL=8  A T->T : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_brun_kl<8><<<tb2, 1024>>>(a, tb2); });
+                printf("KL=8  B run  : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_aseg_kl<64, 0><<<tl, 512>>>(a, b, tl); });
+                printf("KL=64 A T->T : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+                ms = timeit([&] { k_brun_kl<64><<<tb2, 1024>>>(a, tb2); });
+                printf("KL=64 B run  : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+            }
             for (auto& l : ls) {
                 ms = timeit([&] { k_aseg<0, 73984><<<tl, 512>>>(a, b, tl, l.st, l.sk, l.sz, l.sb); });
                 printf("A 8K tile, T%s -> rows: %.3f ms  %.0f GB/s\n", l.name, ms, gb / ms * 1e3);
