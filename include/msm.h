@@ -100,7 +100,7 @@ const char* msm_last_error(const msm_ctx* ctx);   /* ctx may be NULL: last creat
  * kinetic_dt, comoving_boxsize(or 0), transform mode}; the last entry is
  * diagnostic: 0 = three passes per 3-D transform, 2 = the two-pass engine
  * (256^3 double; psi_k is then held transposed internally, downloads are
- * unaffected), 1 = two-pass Poisson solve only (MSM_TWO_PASS=1). */
+ * unaffected; MSM_TWO_PASS=0 in the environment selects the generic engine). */
 int32_t msm_get_derived(const msm_ctx* ctx, double out[8]);
 
 /* Initial conditions.

@@ -739,7 +739,7 @@ __device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* l
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = col[q * tp::A_LINE];
     dft<16, -1, real>(v);
-    const unsigned off = (unsigned)(((((kxh >> 2) * 16 + t.b) * 128 + t.zh) * 4 + (kxh & 3)) * 8 + (tid & 7));
+    const unsigned off = (unsigned)(((((kxh / tp::KL) * 16 + t.b) * 128 + t.zh) * tp::KL + (kxh % tp::KL)) * 8 + (tid & 7));
 #pragma unroll
     for (int q = 0; q < 16; ++q) (wT + (grid_off + (size_t)q * tp::T_TP))[off] = v[q];
 }
@@ -753,7 +753,7 @@ typedef const __attribute__((address_space(1))) real2v* gcptr;
 __device__ __forceinline__ void a_fetch_T(cplx (&v)[16], const TileA& t, const cplx* __restrict__ wT, size_t grid_off) {
     const int tid = threadIdx.x;
     const int kxh = tid >> 3;
-    gcptr p = (gcptr)(wT + grid_off + (size_t)(((((kxh >> 2) * 16 + t.b) * 128 + t.zh) * 4 + (kxh & 3)) * 8 + (tid & 7)));
+    gcptr p = (gcptr)(wT + grid_off + (size_t)(((((kxh / tp::KL) * 16 + t.b) * 128 + t.zh) * tp::KL + (kxh % tp::KL)) * 8 + (tid & 7)));
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const real2v d = *p;
@@ -783,68 +783,6 @@ __device__ __forceinline__ void a_load_twiddles(cplx* tw_lds, const cplx* __rest
     lds_barrier();
 }
 
-// k_invx_rho on A tiles: W leaves as T (x and outer-y stage done).
-template <int DRIFT, int DENS>
-__global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho2(PoisArgs a) {
-    constexpr int N = tp::N, E = 16, TPL = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-
-    double dacc[DENS ? E : 1];
-    if constexpr (DENS) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) dacc[q] = 0.0;
-    }
-    const int pairs = (a.nb + 1) / 2;
-    for (int p = 0; p < pairs; ++p) {
-        const int sa = a.s0 + 2 * p, sb = sa + 1;
-        const bool act_a = a.active[sa] != 0;
-        const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
-        if (!act_a && !act_b) continue;   // uniform over the workgroup
-        real rho[2][E];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool act = h == 0 ? act_a : act_b;
-            if (act) {
-                const int sg = h == 0 ? sa : sb;
-                const cplx* __restrict__ x = a.X + (size_t)(2 * p + h) * a.n3;
-                cplx v[E];
-#pragma unroll
-                for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
-                if constexpr (DRIFT) {
-                    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-#pragma unroll
-                    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-                }
-                LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
-#pragma unroll
-                for (int q = 0; q < E; ++q) {
-                    v[q] = cscale(v[q], a.scale);
-                    const real m2 = v[q].x * v[q].x + v[q].y * v[q].y;
-                    rho[h][q] = a.mass_factor * m2;
-                    if constexpr (DENS) dacc[q] += (double)m2;
-                }
-                lds_barrier();   // exchange reads done before the next run writes
-            } else {
-#pragma unroll
-                for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
-            }
-        }
-        cplx v[E];
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
-        LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
-        a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
-        lds_barrier();
-    }
-    if constexpr (DENS) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];
-    }
-}
-
 // rho from a stored psi on A tiles (first step, msm_potential).
 __global__ __launch_bounds__(tp::A_THREADS) void k_rho_pass2(PoisArgs a) {
     constexpr int N = tp::N, E = 16, TPL = 16;
@@ -871,55 +809,6 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_rho_pass2(PoisArgs a) {
     }
     LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
     a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
-}
-
-// k_kick_fwdx on A tiles: phi_a + i phi_b comes back from T.
-__global__ __launch_bounds__(tp::A_THREADS) void k_kick_fwdx2(PoisArgs a, const real* __restrict__ kick) {
-    constexpr int N = tp::N, E = 16, TPL = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    const bool act_a = a.active[sa] != 0;
-    const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
-    if (!act_a && !act_b) return;
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-
-    real phi[2][E];
-    {
-        cplx vw[E];
-        a_load_T(vw, t, lds, a.W, (size_t)p * a.n3);
-        LineFft<real, N, +1, true>::run(vw, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool act = h == 0 ? act_a : act_b;
-        if (!act) continue;   // uniform over the workgroup
-        const int sg = h == 0 ? sa : sb;
-        cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
-        const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-        const real kc = kick[sg];
-        lds_barrier();   // also keeps the psi loads below the previous transform
-        cplx v[E];
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-        LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            real sn, cs;
-            sincos_t(kc * phi[h][q], &sn, &cs);
-            v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
-        }
-        lds_barrier();
-        LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
-    }
 }
 
 // k_phi_out on A tiles.
@@ -1021,7 +910,7 @@ struct RunB {
     __device__ __forceinline__ RunB() {
         const int tid = threadIdx.x;
         run = blockIdx.x; tpi = run >> 6; kxh = run & 63;
-        off = (size_t)(tpi * 16 + (kxh >> 2)) * 16 * tp::T_B + (kxh & 3) * 8;
+        off = (size_t)(tpi * (64 / tp::KL) + kxh / tp::KL) * 16 * tp::T_B + (kxh % tp::KL) * 8;
         toff = (unsigned)((tid >> 3) * (tp::KL * 8) + (tid & 7));
     }
     __device__ __forceinline__ int kx(const RolesB& r) const { return (kxh << 2) | r.kxl; }
@@ -1565,7 +1454,7 @@ class Engine final : public IEngine {
     void derived(double out[8]) const override {
         out[0] = (double)dx_; out[1] = (double)dx_; out[2] = (double)c_.k2max; out[3] = (double)c_.hbar;
         out[4] = cfg_.total_mass / cfg_.particle_mass;
-        out[5] = (double)kinetic_dt_; out[6] = (double)comoving_box_; out[7] = psi2_ ? 2.0 : (two_pass_ ? 1.0 : 0.0);
+        out[5] = (double)kinetic_dt_; out[6] = (double)comoving_box_; out[7] = two_pass_ ? 2.0 : 0.0;
     }
     int batch() const override { return batch_; }
 
@@ -1587,7 +1476,7 @@ class Engine final : public IEngine {
     void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
     // act = all_active_ solves for finished streams too (standalone msm_potential)
     void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act);
-    // two-pass psi transforms (psi2_): pass B between P and the T-layout scratch X_, pass A between T and a natural grid
+    // two-pass psi transforms (two_pass_): pass B between P and the T-layout scratch X_, pass A between T and a natural grid
     void psi_b(int mode, bool drift, int s0, int n, const int* act, int kind);
     void psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act);
     void first_step_init(int s0, int nb);
@@ -1623,8 +1512,7 @@ class Engine final : public IEngine {
     msm_stream_status* h_status_ = nullptr;
     std::vector<int> host_active_;
     bool fourier_ = false;   // P_ holds psi_k (after the first step)
-    bool two_pass_ = false;  // Poisson solve in two passes over the work array (N = 256, double)
-    bool psi2_ = false;      // psi transforms in two passes as well; psi_k is then kept as P[kx][ky][kz]
+    bool two_pass_ = false;  // every 3-D transform in two passes (N = 256, double); psi_k is then kept as P[kx][ky][kz]
     cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
@@ -1741,11 +1629,8 @@ int Engine::init(std::string& err) {
     c_.inv_n3 = (real)(1.0 / ((double)N_ * N_ * N_));
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
-    two_pass_ = psi2_ = (N_ == tp::N) && sizeof(real) == 8;
-    if (const char* e = getenv("MSM_TWO_PASS")) {   // 0: three passes per transform, 1: two-pass Poisson only
-        two_pass_ = two_pass_ && atoi(e) >= 1;
-        psi2_ = psi2_ && atoi(e) >= 2;
-    }
+    two_pass_ = (N_ == tp::N) && sizeof(real) == 8;
+    if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;   // 0: the generic three-pass engine
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
@@ -1968,7 +1853,7 @@ void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst
 // and move the state to Fourier space (psi_k = F psi, :477-479).
 void Engine::first_step_init(int s0, int nb) {
     poisson_from_psi(P_, false, s0, nb, false, true, st_.active);
-    if (psi2_) {
+    if (two_pass_) {
         psi_a(-1, P_, false, X_, true, s0, nb, st_.active);
         psi_b(PB_FWD, false, s0, nb, st_.active, PK_PLAIN);
     } else {
@@ -1989,7 +1874,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     a.phi = PHI_; a.kick = st_.kick; a.scale = (real)1;
     PoisArgs p = pois_args(s0, nb, st_.active);
 
-    if (psi2_) {
+    if (two_pass_) {
         if constexpr (sizeof(real) == 8) {
             const dim3 gridA(tp::A_TILES), gridAp(tp::A_TILES, (unsigned)((nb + 1) / 2)), blockA(tp::A_THREADS);
             // psi = F^-1[ D psi_k ]: pass B with the whole drift factor, pass A fused with rho and the Poisson pass A
@@ -2016,10 +1901,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     launch_psi<+1, 1, 0>(2, a, nb, PK_INV_Z);
     a.src = X_; a.src_local = 1;
     launch_psi<+1, 1, 0>(1, a, nb, PK_INV_Y);
-    if (two_pass_) {
-        if constexpr (sizeof(real) == 8)
-            timed(PK_INVX_RHO, [&] { k_invx_rho2<1, 0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p); });
-    } else dispatch_n(N_, [&](auto nc) {
+    dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         timed(PK_INVX_RHO, [&] {
@@ -2029,12 +1911,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     // phi at the half-drifted psi, left as F_x[phi_a + i phi_b] in W
     poisson_tail(s0, nb, false, false, false);
     // psi_k = D F[ kick psi ], then on into psi = F^-1[ psi_k ]
-    if (two_pass_) {
-        if constexpr (sizeof(real) == 8)
-            timed(PK_FWD_X, [&] {
-                k_kick_fwdx2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p, st_.kick);
-            });
-    } else dispatch_n(N_, [&](auto nc) {
+    dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         timed(PK_FWD_X, [&] {
@@ -2059,13 +1936,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     // i.e. its density (and the ensemble density if asked for); psi itself is not written back
     launch_psi<+1, 0, 0>(1, a, nb, PK_INV_Y);
     p.dens = step_dens_;
-    if (two_pass_) {
-        if constexpr (sizeof(real) == 8)
-            timed(PK_INVX_RHO, [&] {
-                if (step_dens_) k_invx_rho2<0, 1><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
-                else k_invx_rho2<0, 0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
-            });
-    } else dispatch_n(N_, [&](auto nc) {
+    dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
         const dim3 grid((unsigned)(n3_ / N / G0::LPW)), block(G0::THREADS);
@@ -2157,7 +2028,7 @@ int Engine::potential(int first, int count, std::string& err) {
     if (first < 0 || count < 1 || first + count > ns_) { err = "stream range out of bounds"; return MSM_ERR_INVALID; }
     if (count > 2 * ((batch_ + 1) / 2)) { err = "count exceeds the batch size"; return MSM_ERR_INVALID; }
     if (in_step_) { err = "msm_potential inside an open msm_step_begin"; return MSM_ERR_STATE; }
-    if (fourier_ && psi2_) {
+    if (fourier_ && two_pass_) {
         psi_b(PB_INV, false, first, count, nullptr, PK_PLAIN);
         if constexpr (sizeof(real) == 8) {
             const PoisArgs p = pois_args(first, count, all_active_);
@@ -2229,7 +2100,7 @@ int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
     const cplx* src = P_ + (size_t)s * n3_;
     if (!kspace && fourier_) {
         // psi = F^-1 psi_k (simulation_object.rs:581), materialised on demand in the batch scratch
-        if (psi2_) {
+        if (two_pass_) {
             psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
             psi_a(+1, X_, true, W_, true, s, 1, nullptr);
             src = W_;
@@ -2237,7 +2108,7 @@ int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
             fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
             src = X_;
         }
-    } else if (kspace && psi2_) {
+    } else if (kspace && two_pass_) {
         const unsigned nb32 = (unsigned)(N_ / 32);
         k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(src, X_, N_);
         src = X_;
@@ -2267,7 +2138,7 @@ int Engine::density_sum(void* dev_out, std::string& err) {
     if (in_step_) { err = "msm_density_sum inside an open msm_step_begin"; return MSM_ERR_STATE; }
     if (!fourier_) {
         k_density_sum<<<2048, 256, 0, stream_>>>(P_, n3_, ns_, (double*)dev_out, 0);
-    } else if (psi2_) {
+    } else if (two_pass_) {
         for (int s = 0; s < ns_; ++s) {
             psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
             psi_a(+1, X_, true, W_, true, s, 1, nullptr);
