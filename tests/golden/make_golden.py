@@ -44,6 +44,26 @@ def run(toml, size, which, dtype, nsteps=10, keep=(1, 2, 10)):
     return out
 
 
+COSMO = dict(TOPHAT, sim_name="spherical-tophat-cosmo", final_sim_time=0.6, num_data_dumps=3,
+             cosmology=dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01))
+
+
+def run_dumps(toml, size, expanding, keep):
+    """Whole run of the mean-field stream to final_sim_time (main.rs:61-69); keeps the dumps listed in
+    `keep` (examples/spherical-tophat.toml: 200 dumps; examples/spherical-tophat-cosmo.toml under the
+    feature "expanding", shortened to 3 dumps)."""
+    params = list(o.simulation_iter(dict(toml, size=size), expanding=expanding))[-1]
+    sim = o.SimulationObject(params)
+    sim.dump()
+    while sim.not_finished():
+        sim.update()
+    out = {f"dump_{k}": psi for k, psi in sim.dumps if k in keep}
+    out["n_dumps"] = np.array(len(sim.dumps))
+    out["n_steps"] = np.array(sim.parameters.n_steps)
+    out["final_time"] = np.array(float(sim.parameters.time))
+    return out
+
+
 if __name__ == "__main__":
     jobs = {
         "tophat_n8_f64": (TOPHAT, 8, -1, np.float64),
@@ -52,6 +72,16 @@ if __name__ == "__main__":
         "planewave_n16_mft_f64": (PLANE, 16, -1, np.float64),
         "planewave_n16_wigner1_f64": (PLANE, 16, 0, np.float64),
     }
+    extra = {
+        "tophat_n32_f64": lambda: run(TOPHAT, 32, -1, np.float64, keep=(10,)),
+        "tophat_n16_run200_f64": lambda: run_dumps(TOPHAT, 16, False, (0, 1, 200)),
+        "tophat_cosmo_n16_run3_f64": lambda: run_dumps(COSMO, 16, True, (0, 1, 2, 3)),
+    }
+    for name, fn in extra.items():
+        res = fn()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **res)
+        print(name, os.path.getsize(path) // 1024, "KiB")
     for name, (toml, size, which, dtype) in jobs.items():
         res = run(toml, size, which, dtype)
         path = os.path.join(HERE, name + ".npz")

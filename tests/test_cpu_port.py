@@ -42,7 +42,7 @@ def test_fft_and_potential(N):
 
 
 @pytest.mark.parametrize("name", ["tophat_n8_f64", "tophat_n16_f64", "planewave_n16_mft_f64",
-                                  "planewave_n16_wigner1_f64"])
+                                  "planewave_n16_wigner1_f64", "tophat_n32_f64"])
 def test_golden_vectors(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     base = TOPHAT if name.startswith("tophat") else PLANE
@@ -59,6 +59,24 @@ def test_golden_vectors(name, golden_dir):
             assert rel(sim.get_psi(), g[f"psi_{i}"]) < 1e-11
             sim.potential()
             assert rel(sim.get_phi(), g[f"phi_{i}"]) < 1e-11
+
+
+def test_full_run_golden(golden_dir):
+    # examples/spherical-tophat.toml at its own size 16, mean-field stream, all 200 dumps
+    g = np.load(os.path.join(golden_dir, "tophat_n16_run200_f64.npz"))
+    sim = sp_cpu.CpuSim(16, **TOPHAT)
+    sim.set_psi(g["dump_0"])
+    steps, dumps, t = 0, 0, 0.0
+    while t < TOPHAT["final_sim_time"]:
+        info = sim.update()
+        steps += 1
+        t = info["time"]
+        if info["dump"]:
+            dumps += 1
+            if dumps == 1:
+                assert rel(sim.get_psi(), g["dump_1"]) < 1e-11
+    assert dumps + 1 == int(g["n_dumps"]) == 201 and steps == int(g["n_steps"]) and t == float(g["final_time"])
+    assert rel(sim.get_psi(), g["dump_200"]) < 1e-10
 
 
 def test_dump_schedule():

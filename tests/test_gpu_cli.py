@@ -146,3 +146,27 @@ def test_aliasing_aborts_like_the_reference(tmp_path):
     assert "simulation aliased" in r.stderr and "k2_cutoff = 0.95" in r.stderr
     assert (tmp_path / "sim-data" / "spherical-tophat" / "psi_00000_real").exists()
     assert not (tmp_path / "sim-data" / "spherical-tophat" / "psi_00001_real").exists()
+
+
+def test_full_example_run_against_golden(tmp_path, golden_dir):
+    # examples/spherical-tophat.toml as shipped (size 16, 200 dumps) minus [sampling]: the mean-field stream,
+    # start to finish, against the committed dumps 0, 1 and 200
+    g = np.load(os.path.join(golden_dir, "tophat_n16_run200_f64.npz"))
+    cfg = dict(axis_length=30.0, final_sim_time=40.0, cfl=0.5, num_data_dumps=200, total_mass=1e11, hbar_=0.05,
+               sim_name="spherical-tophat", k2_cutoff=0.95, alias_threshold=0.02, dims=3, size=16,
+               ics=dict(type="SphericalTophat", radius=5.0, slope=50.0, delta=100.0))
+    run_cli(tmp_path, cfg)
+    for k, tol in ((0, 1e-14), (1, 1e-11), (200, 1e-10)):
+        assert rel(load_dump(tmp_path, "spherical-tophat", k), g[f"dump_{k}"]) < tol, k
+    assert not (tmp_path / "sim-data" / "spherical-tophat" / "psi_00201_real").exists()
+
+
+def test_expanding_run_against_golden(tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tophat_cosmo_n16_run3_f64.npz"))
+    cfg = dict(axis_length=30.0, final_sim_time=0.6, cfl=0.5, num_data_dumps=3, total_mass=1e11, hbar_=0.05,
+               sim_name="spherical-tophat-cosmo", k2_cutoff=0.95, alias_threshold=0.02, dims=3, size=16,
+               ics=dict(type="SphericalTophat", radius=5.0, slope=50.0, delta=100.0),
+               cosmology=dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01))
+    run_cli(tmp_path, cfg, "--expanding")
+    for k in range(4):
+        assert rel(load_dump(tmp_path, "spherical-tophat-cosmo", k), g[f"dump_{k}"]) < 1e-11, k

@@ -168,7 +168,7 @@ def test_static_steps_128_f64():
 
 
 @pytest.mark.parametrize("name", ["tophat_n8_f64", "tophat_n16_f64", "planewave_n16_mft_f64",
-                                  "planewave_n16_wigner1_f64", "tophat_n16_f32"])
+                                  "planewave_n16_wigner1_f64", "tophat_n16_f32", "tophat_n32_f64"])
 def test_golden_vectors(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     base = TOPHAT if name.startswith("tophat") else PLANE

@@ -175,3 +175,19 @@ def test_goldens_regenerate(golden_dir):
     for i in range(2):
         sim.update()
     assert np.allclose(sim.psi, g["psi_2"], rtol=0, atol=1e-13)
+
+
+def test_expanding_golden_regenerates(golden_dir):
+    # the committed expanding-box run (examples/spherical-tophat-cosmo.toml, shortened) is what the oracle produces today
+    g = np.load(os.path.join(golden_dir, "tophat_cosmo_n16_run3_f64.npz"))
+    toml = dict(axis_length=30.0, final_sim_time=0.6, cfl=0.5, num_data_dumps=3, total_mass=1e11, hbar_=0.05,
+                sim_name="spherical-tophat-cosmo", k2_cutoff=0.95, alias_threshold=0.02, dims=3, size=16,
+                ics=dict(type="SphericalTophat", radius=5.0, slope=50.0, delta=100.0),
+                cosmology=dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01))
+    sim = o.SimulationObject(list(o.simulation_iter(toml, expanding=True))[-1])
+    sim.dump()
+    while sim.not_finished():
+        sim.update()
+    assert len(sim.dumps) == int(g["n_dumps"]) == 4 and sim.parameters.n_steps == int(g["n_steps"])
+    for k, psi in sim.dumps:
+        assert np.allclose(psi, g[f"dump_{k}"], rtol=0, atol=1e-13)
