@@ -85,7 +85,7 @@ def cpu_baseline(size, seconds_cap=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--streams", type=int, default=256, help="total streams over all GPUs")

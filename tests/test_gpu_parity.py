@@ -422,6 +422,40 @@ def test_two_pass_engine_matches_three_pass_256(cosmology):
         assert rel_err(phi2[s], phi3[s]) < 1e-11
 
 
+def test_config5_shape_512_f32_expanding():
+    """512^3 fp32, expanding box (the largest BASELINE configuration, one pair of streams): runs on the
+    generic three-pass engine.  Oracle-free properties: Parseval and round trip at fp32 accuracy,
+    the two streams of a pair (real / imaginary lane of one Poisson solve) stay equal to fp32 rounding,
+    the step conserves the norm, dt obeys the kinetic bound."""
+    N = 512
+    cosmo = dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01)
+    rng = np.random.default_rng(5)
+    psi = (1.0 + 0.05 * rng.standard_normal((N, N, N), dtype=np.float32)
+           + 0.05j * rng.standard_normal((N, N, N), dtype=np.float32)).astype(np.complex64)
+    with Evolver(size=N, n_streams=2, precision="f32", cosmology=cosmo, **dict(TOPHAT, cfl=0.05)) as ev:
+        d = ev.derived()
+        dv = d["dx"] ** 3
+        psi *= np.float32(1.0 / np.sqrt(np.sum(np.abs(psi).astype(np.float64) ** 2) * dv))
+        ev.set_psi(0, psi)
+        ev.copy_psi(1, 0)
+        ev.forward(0)
+        k = ev.get_psi(0)
+        assert abs(np.sum(np.abs(k).astype(np.float64) ** 2) / np.sum(np.abs(psi).astype(np.float64) ** 2) - 1) < 1e-5
+        ev.inverse(0)
+        assert rel_err(ev.get_psi(0), psi) < 2e-5
+        ev.copy_psi(0, 1)
+        for _ in range(2):
+            ev.step_begin([0.5, 0.5], [1e9, 1e9])
+            st = ev.status()
+            assert st[0].dt == st[1].dt and 0 < st[0].dt <= d["kinetic_dt"] * (1 + 1e-6)
+            ev.step_end([0.5, 0.5], [s.time + s.dt for s in st], [s.tau + s.dt for s in st], [0.0, 0.0])
+        a, b = ev.get_psi(0), ev.get_psi(1)
+        assert rel_err(a, b) < 2e-5
+        assert abs(np.sum(np.abs(a).astype(np.float64) ** 2) * dv - 1) < 1e-4
+        st = ev.status()
+        assert st[0].n_steps == 2 and st[0].aliased == 0 and st[0].active == 1
+
+
 _DENSITY_SCRIPT = r"""
 import sys
 import numpy as np
