@@ -165,6 +165,28 @@ int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64);
  * streams it advanced, accumulated inside the step's last pass at no extra HBM read. */
 int32_t msm_step_density(msm_ctx* ctx, void* device_out_f64);
 
+/* In-situ synthesizer (synthesizer/src/main.rs:63-93,161-187; lib.rs:190-300): the per-dump
+ * ensemble products the reference's post-processor builds by re-reading every stream's dump from
+ * disk.  A slot holds four running sums over streams, each N^dims complex doubles, in the dump
+ * file's element order:  psi,  |psi|^2,  psik,  |psik|^2,  where psik is the UN-NORMALISED forward
+ * transform of psi, as the synthesizer's ndrustfft computes it (= N^{dims/2} times the simulator's
+ * unitary psi_k).
+ * msm_synth_accumulate: add stream `stream`'s current psi to slot `slot` (slots are created zeroed
+ *   on first use; one slot per dump index in flight).
+ * msm_synth_device: the slot's device buffer (4 * N^dims complex doubles, sums not means) and the
+ *   number of streams accumulated -- for a caller that all-reduces both over its GPUs; after such a
+ *   reduction msm_synth_set_count tells the library the global count.
+ * msm_synth_fetch: mean field `field` (MSM_SYNTH_PSI ...) to two host planes of doubles.
+ * msm_synth_qx: Qx = sum( <|psi|^2> - |<psi>|^2 ) * dv  (main.rs:161-175), dv = dx^dims.
+ * msm_synth_release: free the slot. */
+enum msm_synth_field { MSM_SYNTH_PSI = 0, MSM_SYNTH_PSI2 = 1, MSM_SYNTH_PSIK = 2, MSM_SYNTH_PSIK2 = 3 };
+int32_t msm_synth_accumulate(msm_ctx* ctx, int32_t stream, int32_t slot);
+int32_t msm_synth_device(msm_ctx* ctx, int32_t slot, void** device_sums, int64_t* count);
+int32_t msm_synth_set_count(msm_ctx* ctx, int32_t slot, int64_t count);
+int32_t msm_synth_fetch(msm_ctx* ctx, int32_t slot, int32_t field, double* re, double* im);
+int32_t msm_synth_qx(msm_ctx* ctx, int32_t slot, double* qx_re, double* qx_im);
+int32_t msm_synth_release(msm_ctx* ctx, int32_t slot);
+
 /* Timing helper for benchmarks: HIP events on the context's stream. */
 int32_t msm_timer_start(msm_ctx* ctx);
 int32_t msm_timer_stop_ms(msm_ctx* ctx, float* ms);

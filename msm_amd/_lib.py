@@ -66,6 +66,12 @@ SYMBOLS = {
     "msm_get_potential": (C.c_int32, [_P, C.c_int32, _P]),
     "msm_density_sum": (C.c_int32, [_P, _P]),
     "msm_step_density": (C.c_int32, [_P, _P]),
+    "msm_synth_accumulate": (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    "msm_synth_device": (C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "msm_synth_set_count": (C.c_int32, [_P, C.c_int32, C.c_int64]),
+    "msm_synth_fetch": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "msm_synth_qx": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "msm_synth_release": (C.c_int32, [_P, C.c_int32]),
     "msm_timer_start": (C.c_int32, [_P]),
     "msm_timer_stop_ms": (C.c_int32, [_P, C.POINTER(C.c_float)]),
     "msm_profile": (C.c_int32, [_P, C.c_int32]),

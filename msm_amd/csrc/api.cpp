@@ -135,6 +135,33 @@ int32_t msm_step_density(msm_ctx* ctx, void* device_out_f64) {
     MSM_CHECK_CTX(ctx);
     return ctx->eng->step_density(device_out_f64, ctx->err);
 }
+int32_t msm_synth_accumulate(msm_ctx* ctx, int32_t stream, int32_t slot) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->synth_accumulate(stream, slot, ctx->err);
+}
+int32_t msm_synth_device(msm_ctx* ctx, int32_t slot, void** device_sums, int64_t* count) {
+    MSM_CHECK_CTX(ctx);
+    long long c = 0;
+    const int rc = ctx->eng->synth_device(slot, device_sums, &c, ctx->err);
+    if (count) *count = c;
+    return rc;
+}
+int32_t msm_synth_set_count(msm_ctx* ctx, int32_t slot, int64_t count) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->synth_set_count(slot, count, ctx->err);
+}
+int32_t msm_synth_fetch(msm_ctx* ctx, int32_t slot, int32_t field, double* re, double* im) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->synth_fetch(slot, field, re, im, ctx->err);
+}
+int32_t msm_synth_qx(msm_ctx* ctx, int32_t slot, double* qx_re, double* qx_im) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->synth_qx(slot, qx_re, qx_im, ctx->err);
+}
+int32_t msm_synth_release(msm_ctx* ctx, int32_t slot) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->synth_release(slot, ctx->err);
+}
 int32_t msm_timer_start(msm_ctx* ctx) {
     MSM_CHECK_CTX(ctx);
     return ctx->eng->timer_start(ctx->err);

@@ -1391,6 +1391,43 @@ __global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, dou
     }
 }
 
+// In-situ synthesizer sums (synthesizer/src/main.rs:63-93): acc = [psi | |psi|^2 | psik | |psik|^2], each n complex
+// doubles; psik arrives unitary and is scaled to the synthesizer's un-normalised transform.
+__global__ void k_synth_acc(const cplx* __restrict__ psi, const cplx* __restrict__ psik, double2* __restrict__ acc, size_t n,
+                            double kscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double pr = (double)psi[i].x, pi = (double)psi[i].y;
+        const double kr = (double)psik[i].x * kscale, ki = (double)psik[i].y * kscale;
+        double2 a = acc[i]; a.x += pr; a.y += pi; acc[i] = a;
+        double2 b = acc[n + i]; b.x += pr * pr + pi * pi; acc[n + i] = b;
+        double2 c = acc[2 * n + i]; c.x += kr; c.y += ki; acc[2 * n + i] = c;
+        double2 d = acc[3 * n + i]; d.x += kr * kr + ki * ki; acc[3 * n + i] = d;
+    }
+}
+// mean of one field to two real planes
+__global__ void k_synth_mean(const double2* __restrict__ f, double* __restrict__ re, double* __restrict__ im, size_t n, double inv) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 v = f[i];
+        re[i] = v.x * inv;
+        im[i] = v.y * inv;
+    }
+}
+// per-block partials of sum( <psi2> - |<psi>|^2 ), complex (main.rs:161-175)
+__global__ __launch_bounds__(256) void k_synth_qx(const double2* __restrict__ acc, size_t n, double inv, double2* __restrict__ partial) {
+    __shared__ double red[256];
+    double sr = 0.0, si = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double2 p = acc[i], p2 = acc[n + i];
+        const double mr = p.x * inv, mi = p.y * inv;
+        sr += p2.x * inv - (mr * mr + mi * mi);
+        si += p2.y * inv;
+    }
+    const double tr = block_sum<256>(sr, red);
+    __syncthreads();
+    const double ti = block_sum<256>(si, red);
+    if (threadIdx.x == 0) { partial[blockIdx.x].x = tr; partial[blockIdx.x].y = ti; }
+}
+
 // ---------------------------------------------------------------------------
 // size dispatch
 // ---------------------------------------------------------------------------
@@ -1447,6 +1484,12 @@ class Engine final : public IEngine {
     int get_potential(int s, void* phi, std::string& err) override;
     int density_sum(void* dev_out, std::string& err) override;
     int step_density(void* dev_out, std::string& err) override;
+    int synth_accumulate(int s, int slot, std::string& err) override;
+    int synth_device(int slot, void** dev, long long* count, std::string& err) override;
+    int synth_set_count(int slot, long long count, std::string& err) override;
+    int synth_fetch(int slot, int field, double* re, double* im, std::string& err) override;
+    int synth_qx(int slot, double* re, double* im, std::string& err) override;
+    int synth_release(int slot, std::string& err) override;
     int timer_start(std::string& err) override;
     int timer_stop(float* ms, std::string& err) override;
     int profile(int enable, std::string& err) override;
@@ -1517,6 +1560,14 @@ class Engine final : public IEngine {
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
+    struct SynthSlot { double2* sums = nullptr; long long count = 0; };
+    std::vector<SynthSlot> synth_;
+    int synth_check(int slot, std::string& err) const {
+        if (slot < 0 || slot >= (int)synth_.size() || !synth_[slot].sums) { err = "synthesizer slot is not open"; return MSM_ERR_INVALID; }
+        return MSM_OK;
+    }
+    // psi (natural order) and unitary psi_k (reference order) of stream s on the device; valid until the next call
+    void materialise(int s, const cplx** psi, const cplx** psik);
 
     // optional per-launch timing (HIP events on the launch stream), bucketed by pass kind
     struct ProfRec { int kind; hipEvent_t a, b; };
@@ -1540,6 +1591,8 @@ class Engine final : public IEngine {
 };
 
 void Engine::release() {
+    for (auto& sl : synth_) if (sl.sums) (void)hipFree(sl.sums);
+    synth_.clear();
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
     if (h_status_) (void)hipHostFree(h_status_);
@@ -2183,6 +2236,105 @@ int Engine::profile_report(int max_kinds, double* total_ms, long long* launches,
     }
     prof_.clear();
     *n_kinds = PK_COUNT;
+    return MSM_OK;
+}
+
+void Engine::materialise(int s, const cplx** psi, const cplx** psik) {
+    if (!fourier_) {
+        // before the first step P_ holds psi; psi_k = F psi (simulation_object.rs:477-479) into the scratch
+        fft3_plain(P_, false, X_, true, s, 1, -1, nullptr);
+        *psi = P_ + (size_t)s * n3_;
+        *psik = X_;
+    } else if (two_pass_) {
+        psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
+        psi_a(+1, X_, true, W_, true, s, 1, nullptr);
+        const unsigned nb32 = (unsigned)(N_ / 32);
+        k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(P_ + (size_t)s * n3_, X_, N_);
+        *psi = W_;
+        *psik = X_;
+    } else {
+        fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
+        *psi = X_;
+        *psik = P_ + (size_t)s * n3_;
+    }
+}
+
+int Engine::synth_accumulate(int s, int slot, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (slot < 0 || slot > 65535) { err = "synthesizer slot out of range"; return MSM_ERR_INVALID; }
+    if (in_step_) { err = "msm_synth_accumulate inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    if ((int)synth_.size() <= slot) synth_.resize(slot + 1);
+    SynthSlot& sl = synth_[slot];
+    if (!sl.sums) {
+        HIP_TRY(hipMalloc((void**)&sl.sums, sizeof(double2) * 4 * n3_));
+        HIP_TRY(hipMemsetAsync(sl.sums, 0, sizeof(double2) * 4 * n3_, stream_));
+        sl.count = 0;
+    }
+    const cplx *psi = nullptr, *psik = nullptr;
+    materialise(s, &psi, &psik);
+    k_synth_acc<<<2048, 256, 0, stream_>>>(psi, psik, sl.sums, n3_, std::pow((double)N_, dims_ / 2.0));
+    sl.count += 1;
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::synth_device(int slot, void** dev, long long* count, std::string& err) {
+    if (int rc = synth_check(slot, err)) return rc;
+    HIP_TRY(hipStreamSynchronize(stream_));   // the caller hands the buffer to another library
+    if (dev) *dev = synth_[slot].sums;
+    if (count) *count = synth_[slot].count;
+    return MSM_OK;
+}
+
+int Engine::synth_set_count(int slot, long long count, std::string& err) {
+    if (int rc = synth_check(slot, err)) return rc;
+    if (count < 1) { err = "count must be >= 1"; return MSM_ERR_INVALID; }
+    synth_[slot].count = count;
+    return MSM_OK;
+}
+
+int Engine::synth_fetch(int slot, int field, double* re, double* im, std::string& err) {
+    if (int rc = synth_check(slot, err)) return rc;
+    if (field < 0 || field > 3 || !re || !im) { err = "bad field or null plane"; return MSM_ERR_INVALID; }
+    if (synth_[slot].count < 1) { err = "nothing accumulated"; return MSM_ERR_STATE; }
+    double* stage = nullptr;   // two double planes: fp32 contexts have a smaller staging grid, so use a scratch of our own
+    HIP_TRY(hipMalloc((void**)&stage, sizeof(double) * 2 * n3_));
+    k_synth_mean<<<2048, 256, 0, stream_>>>(synth_[slot].sums + (size_t)field * n3_, stage, stage + n3_, n3_,
+                                            1.0 / (double)synth_[slot].count);
+    hipError_t e1 = hipMemcpyAsync(re, stage, sizeof(double) * n3_, hipMemcpyDeviceToHost, stream_);
+    hipError_t e2 = hipMemcpyAsync(im, stage + n3_, sizeof(double) * n3_, hipMemcpyDeviceToHost, stream_);
+    hipError_t e3 = hipStreamSynchronize(stream_);
+    (void)hipFree(stage);
+    HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
+    return MSM_OK;
+}
+
+int Engine::synth_qx(int slot, double* re, double* im, std::string& err) {
+    if (int rc = synth_check(slot, err)) return rc;
+    if (!re || !im) { err = "null output"; return MSM_ERR_INVALID; }
+    if (synth_[slot].count < 1) { err = "nothing accumulated"; return MSM_ERR_STATE; }
+    constexpr int NB = 1024;
+    double2* part = nullptr;
+    HIP_TRY(hipMalloc((void**)&part, sizeof(double2) * NB));
+    k_synth_qx<<<NB, 256, 0, stream_>>>(synth_[slot].sums, n3_, 1.0 / (double)synth_[slot].count, part);
+    std::vector<double2> h(NB);
+    hipError_t e1 = hipMemcpyAsync(h.data(), part, sizeof(double2) * NB, hipMemcpyDeviceToHost, stream_);
+    hipError_t e2 = hipStreamSynchronize(stream_);
+    (void)hipFree(part);
+    HIP_TRY(e1); HIP_TRY(e2);
+    double sr = 0.0, si = 0.0;
+    for (int i = 0; i < NB; ++i) { sr += h[i].x; si += h[i].y; }   // fixed order
+    const double dv = std::pow((double)dx_, (double)dims_);
+    *re = sr * dv;
+    *im = si * dv;
+    return MSM_OK;
+}
+
+int Engine::synth_release(int slot, std::string& err) {
+    if (int rc = synth_check(slot, err)) return rc;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    (void)hipFree(synth_[slot].sums);
+    synth_[slot] = SynthSlot{};
     return MSM_OK;
 }
 

@@ -25,6 +25,12 @@ struct IEngine {
     virtual int get_potential(int s, void* phi, std::string& err) = 0;
     virtual int density_sum(void* dev_out, std::string& err) = 0;
     virtual int step_density(void* dev_out, std::string& err) = 0;
+    virtual int synth_accumulate(int s, int slot, std::string& err) = 0;
+    virtual int synth_device(int slot, void** dev, long long* count, std::string& err) = 0;
+    virtual int synth_set_count(int slot, long long count, std::string& err) = 0;
+    virtual int synth_fetch(int slot, int field, double* re, double* im, std::string& err) = 0;
+    virtual int synth_qx(int slot, double* re, double* im, std::string& err) = 0;
+    virtual int synth_release(int slot, std::string& err) = 0;
     virtual int timer_start(std::string& err) = 0;
     virtual int timer_stop(float* ms, std::string& err) = 0;
     virtual int profile(int enable, std::string& err) = 0;

@@ -4,9 +4,11 @@
 // (main.rs:43-79), this driver advances them together in one device context.
 //
 //   msm-simulator --toml <path> [-v|--verbose] [--test]
-//                 [--expanding] [--precision f64|f32] [--device N] [--batch B]
+//                 [--expanding] [--precision f64|f32] [--device N] [--batch B] [--synthesize]
 //
 // --expanding stands for the reference's cargo feature of the same name (compile-time there).
+// --synthesize also writes the msm-synthesizer's products (synthesizer/src/main.rs:63-187) for the seed
+//   streams, accumulated on the device as each stream reaches a dump: sim-data/{sim_name}-combined/.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -33,14 +35,14 @@ const char* SIM_DATA_FOLDER = "sim-data";           // simulation_object.rs:1116
 
 struct Args {
     std::string toml;
-    bool verbose = false, test = false, expanding = false;
+    bool verbose = false, test = false, expanding = false, synthesize = false;
     int precision = MSM_F64, device = 0, batch = 0;
 };
 
 [[noreturn]] void usage(const char* why) {
     std::fprintf(stderr, "error: %s\n\nUSAGE:\n    msm-simulator [OPTIONS] --toml <TOML>\n\nOPTIONS:\n"
                          "    -t, --toml <TOML>\n    -v, --verbose\n        --test\n        --expanding\n"
-                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n", why);
+                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n", why);
     std::exit(2);
 }
 
@@ -57,6 +59,7 @@ Args parse_args(int argc, char** argv) {
         else if (s == "--verbose" || s == "-v") a.verbose = true;
         else if (s == "--test") a.test = true;
         else if (s == "--expanding") a.expanding = true;
+        else if (s == "--synthesize") a.synthesize = true;
         else if (s == "--precision") { const std::string p = val(); if (p == "f64") a.precision = MSM_F64; else if (p == "f32") a.precision = MSM_F32; else usage("--precision takes f64 or f32"); }
         else if (s == "--device") a.device = std::atoi(val().c_str());
         else if (s == "--batch") a.batch = std::atoi(val().c_str());
@@ -197,7 +200,30 @@ int run(const Args& args) {
             writers.submit<T>(dir + name, std::move(phi), std::move(zero), shape);
         }
     };
-    for (int s = 0; s < ns; ++s) dump(s, 0);   // main.rs:61
+    // ---- in-situ synthesizer (synthesizer/src/main.rs:63-187): seed streams only, the last entry is the mean-field run
+    const int n_seed_streams = ns - 1;
+    std::vector<int> synth_count(toml.num_data_dumps + 1, 0);
+    std::vector<std::pair<double, double>> qx(toml.num_data_dumps + 1, {0.0, 0.0});
+    std::vector<char> qx_done(toml.num_data_dumps + 1, 0);
+    const std::string combined = std::string(SIM_DATA_FOLDER) + "/" + toml.sim_name + "-combined";
+    auto synthesize = [&](int s, int k) {
+        if (!args.synthesize || s >= n_seed_streams || k < 0 || k > (int)toml.num_data_dumps) return;
+        check(ctx, msm_synth_accumulate(ctx, s, k), "msm_synth_accumulate");
+        if (++synth_count[k] < n_seed_streams) return;
+        std::filesystem::create_directories(combined);
+        static const char* fields[4] = {"psi", "psi2", "psik", "psik2"};
+        for (int f = 0; f < 4; ++f) {
+            char name[64];
+            std::snprintf(name, sizeof name, "/%s_%05d", fields[f], k);
+            std::vector<double> re(n_cells), im(n_cells);
+            check(ctx, msm_synth_fetch(ctx, k, f, re.data(), im.data()), "msm_synth_fetch");
+            writers.submit<double>(combined + name, std::move(re), std::move(im), shape);
+        }
+        check(ctx, msm_synth_qx(ctx, k, &qx[k].first, &qx[k].second), "msm_synth_qx");
+        qx_done[k] = 1;
+        check(ctx, msm_synth_release(ctx, k), "msm_synth_release");
+    };
+    for (int s = 0; s < ns; ++s) { dump(s, 0); synthesize(s, 0); }   // main.rs:61
 
     // ---- expanding-box host state (simulation_object.rs:726-760, :939-990)
     std::vector<ScaleFactorSolver> solvers;
@@ -266,6 +292,7 @@ int run(const Args& args) {
             tau[s] = (T)st[s].tau;
             if (st[s].dump) {
                 dump(s, st[s].current_dumps);
+                synthesize(s, st[s].current_dumps);
                 if (args.expanding) std::printf("(%s) z = %g  [%d/%u]\n", streams[s].sim_name.c_str(), 1.0 / solvers[s].get_a() - 1.0, st[s].current_dumps, toml.num_data_dumps);
                 else std::printf("(%s) t = %g  [%d/%u]\n", streams[s].sim_name.c_str(), st[s].time, st[s].current_dumps, toml.num_data_dumps);
             }
@@ -274,6 +301,16 @@ int run(const Args& args) {
                             (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_loop).count());
         }
         prev = st;
+    }
+    if (args.synthesize && n_seed_streams > 0) {
+        // Qx time series over the dumps (post_combine, synthesizer/src/lib.rs:351-609), shape (n_dumps + 1, 1, 1, 1)
+        std::vector<double> re, im;
+        for (size_t k = 0; k < qx.size(); ++k)
+            if (qx_done[k]) { re.push_back(qx[k].first); im.push_back(qx[k].second); }
+        if (!re.empty()) {
+            const std::vector<size_t> qshape = {re.size(), 1, 1, 1};
+            writers.submit<double>(combined + "/Qx", std::move(re), std::move(im), qshape);
+        }
     }
     writers.drain(true);
     msm_destroy(ctx);

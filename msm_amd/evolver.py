@@ -179,6 +179,36 @@ class Evolver:
     def step_density(self, device_ptr):
         self._check(self._lib.msm_step_density(self._ctx, device_ptr), "msm_step_density")
 
+    # -- in-situ synthesizer (synthesizer/src/main.rs:63-93,161-187) -------
+    SYNTH_FIELDS = ("psi", "psi2", "psik", "psik2")
+
+    def synth_accumulate(self, stream: int, slot: int):
+        self._check(self._lib.msm_synth_accumulate(self._ctx, stream, slot), "msm_synth_accumulate")
+
+    def synth_device(self, slot: int):
+        """(device pointer of the 4 * N^dims complex128 sums, streams accumulated)"""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._check(self._lib.msm_synth_device(self._ctx, slot, C.byref(ptr), C.byref(cnt)), "msm_synth_device")
+        return ptr.value, cnt.value
+
+    def synth_set_count(self, slot: int, count: int):
+        self._check(self._lib.msm_synth_set_count(self._ctx, slot, count), "msm_synth_set_count")
+
+    def synth_fetch(self, slot: int, field: str) -> np.ndarray:
+        re = np.empty(self.shape, dtype=np.float64)
+        im = np.empty(self.shape, dtype=np.float64)
+        self._check(self._lib.msm_synth_fetch(self._ctx, slot, self.SYNTH_FIELDS.index(field), re.ctypes.data,
+                                              im.ctypes.data), "msm_synth_fetch")
+        return re + 1j * im
+
+    def synth_qx(self, slot: int) -> complex:
+        re, im = C.c_double(), C.c_double()
+        self._check(self._lib.msm_synth_qx(self._ctx, slot, C.byref(re), C.byref(im)), "msm_synth_qx")
+        return complex(re.value, im.value)
+
+    def synth_release(self, slot: int):
+        self._check(self._lib.msm_synth_release(self._ctx, slot), "msm_synth_release")
+
     def timer_start(self):
         self._check(self._lib.msm_timer_start(self._ctx), "msm_timer_start")
 

@@ -668,3 +668,20 @@ def write_dump(dirpath: str, k: int, psi: np.ndarray):
     for part, arr in (("real", psi.real), ("imag", psi.imag)):
         with open(os.path.join(dirpath, f"psi_{k:05d}_{part}"), "wb") as f:
             np.save(f, np.ascontiguousarray(arr).reshape(shape))
+
+
+# ---------------------------------------------------------------------------
+# synthesizer (synthesizer/src/main.rs:63-93,161-187; lib.rs:190-300)
+# ---------------------------------------------------------------------------
+def reference_synthesis(dumps_by_stream, dv: float):
+    """analyze_sims + the Qx post-combine for ONE dump index: dumps_by_stream = list of psi arrays
+    (one per stream, the mean-field run excluded).  The transform is ndrustfft's ndfft along every
+    axis, i.e. un-normalised."""
+    n = len(dumps_by_stream)
+    psi = sum(dumps_by_stream) / n
+    psi2 = sum(np.abs(p) ** 2 for p in dumps_by_stream) / n
+    ks = [np.fft.fftn(p) for p in dumps_by_stream]
+    psik = sum(ks) / n
+    psik2 = sum(np.abs(k) ** 2 for k in ks) / n
+    qx = np.sum(psi2 - np.abs(psi) ** 2) * dv
+    return dict(psi=psi, psi2=psi2.astype(np.complex128), psik=psik, psik2=psik2.astype(np.complex128), Qx=complex(qx))

@@ -170,3 +170,23 @@ def test_expanding_run_against_golden(tmp_path, golden_dir):
     run_cli(tmp_path, cfg, "--expanding")
     for k in range(4):
         assert rel(load_dump(tmp_path, "spherical-tophat-cosmo", k), g[f"dump_{k}"]) < 1e-11, k
+
+
+def test_synthesize_flag_matches_post_processing(tmp_path):
+    # --synthesize: the -combined/ products equal the reference synthesizer's arithmetic applied to the
+    # stream dumps this very run wrote (synthesizer/src/main.rs:63-187); the mean-field run is excluded
+    cfg = dict(TOPHAT, sampling=dict(seeds="1 to 3", scheme="Husimi"))
+    run_cli(tmp_path, cfg, "--synthesize")
+    names = [f"spherical-tophat-stream{seed:05d}" for seed in (1, 2, 3)]
+    dv = (cfg["axis_length"] / cfg["size"]) ** 3
+    qx = load_dump(tmp_path, "spherical-tophat-combined", 0, "psi")  # placeholder to assert layout below
+    assert qx.shape == (16, 16, 16)
+    with open(tmp_path / "sim-data" / "spherical-tophat-combined" / "Qx_real", "rb") as f:
+        qre = np.load(f)
+    assert qre.shape == (cfg["num_data_dumps"] + 1, 1, 1, 1)
+    for k in range(cfg["num_data_dumps"] + 1):
+        want = o.reference_synthesis([load_dump(tmp_path, n, k) for n in names], dv)
+        for field in ("psi", "psi2", "psik", "psik2"):
+            got = load_dump(tmp_path, "spherical-tophat-combined", k, field)
+            assert rel(got, want[field]) < 1e-12, (k, field)
+        assert abs(qre[k, 0, 0, 0] - want["Qx"].real) < 1e-12

@@ -64,3 +64,88 @@ def test_density_allreduce_two_ranks(tmp_path):
     for seed in range(1, n_streams + 1):
         want += (np.abs(o.sample_quantum_perturbation(base, 60.0 / N, 3, 3e16, 3e6, "Wigner", seed)) ** 2).reshape(-1)
     assert np.allclose(got, want, rtol=1e-14, atol=0)
+
+
+class _FakeSynthEvolver:
+    """Host stand-in with the Evolver's synth_* surface, numpy sums (driver logic only)."""
+
+    def __init__(self, psis, N):
+        self.psis, self.shape, self.slots = psis, (N, N, N), {}
+
+    def synth_accumulate(self, stream, slot):
+        n3 = int(np.prod(self.shape))
+        sums, cnt = self.slots.setdefault(slot, [np.zeros(4 * n3, dtype=np.complex128), 0])
+        p = self.psis[stream].reshape(-1)
+        k = np.fft.fftn(self.psis[stream]).reshape(-1)
+        sums[0:n3] += p
+        sums[n3:2 * n3] += np.abs(p) ** 2
+        sums[2 * n3:3 * n3] += k
+        sums[3 * n3:] += np.abs(k) ** 2
+        self.slots[slot][1] = cnt + 1
+
+    def synth_device(self, slot):
+        return self.slots[slot][0], self.slots[slot][1]
+
+    def synth_set_count(self, slot, count):
+        self.slots[slot][1] = count
+
+    def synth_fetch(self, slot, field):
+        from msm_amd.synth import FIELDS
+        n3, i = int(np.prod(self.shape)), FIELDS.index(field)
+        return (self.slots[slot][0][i * n3:(i + 1) * n3] / self.slots[slot][1]).reshape(self.shape)
+
+    def synth_qx(self, slot):
+        n3, (sums, cnt) = int(np.prod(self.shape)), self.slots[slot]
+        return complex(np.sum(sums[n3:2 * n3] / cnt - np.abs(sums[:n3] / cnt) ** 2) * 0.5)
+
+    def synth_release(self, slot):
+        del self.slots[slot]
+
+
+def _synth_worker(rank, world, port, n_streams, N, root_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    from msm_amd.sharding import partition_streams
+    from msm_amd.synth import InSituSynthesizer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = partition_streams(n_streams, world, rank)
+    rng = np.random.default_rng(0)
+    allpsi = [rng.standard_normal((N, N, N)) + 1j * rng.standard_normal((N, N, N)) for _ in range(n_streams)]
+    ev = _FakeSynthEvolver(allpsi[first:first + count], N)
+    syn = InSituSynthesizer(ev, "run", n_streams, 1, out_root=root_dir, dist=dist,
+                            to_tensor=lambda arr, n: torch.from_numpy(arr.view(np.float64)))
+    for dump in (0, 1):
+        for s in range(count):
+            syn.add(s, dump)
+        assert syn.ready(dump, count)
+        syn.finish(dump)
+    syn.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_situ_synthesizer_two_ranks(tmp_path):
+    """The synthesizer driver over two ranks (3 + 2 streams): sums and counts are all-reduced,
+    rank 0 writes the reference's `-combined/` layout."""
+    import torch.multiprocessing as mp
+    import sp_oracle as o
+
+    n_streams, N = 5, 8
+    mp.spawn(_synth_worker, args=(2, _free_port(), n_streams, N, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(0)
+    allpsi = [rng.standard_normal((N, N, N)) + 1j * rng.standard_normal((N, N, N)) for _ in range(n_streams)]
+    want = o.reference_synthesis(allpsi, 0.5)
+    base = tmp_path / "sim-data" / "run-combined"
+    for f in ("psi", "psi2", "psik", "psik2"):
+        for dump in (0, 1):
+            re = np.load(open(base / f"{f}_{dump:05d}_real", "rb"))
+            im = np.load(open(base / f"{f}_{dump:05d}_imag", "rb"))
+            assert re.shape == (N, N, N, 1) and re.dtype == np.float64
+            assert np.allclose(re[..., 0] + 1j * im[..., 0], want[f], rtol=1e-12, atol=1e-12)
+    qx = np.load(open(base / "Qx_real", "rb"))
+    assert qx.shape == (2, 1, 1, 1) and np.allclose(qx[:, 0, 0, 0], want["Qx"].real, rtol=1e-12)
