@@ -112,8 +112,9 @@ int32_t msm_get_derived(const msm_ctx* ctx, double out[8]);
  * msm_copy_psi: device copy stream src -> dst (every stream starts from the
  *   same mean-field psi before sampling, simulation_object.rs:406-435).
  * msm_sample: Wigner/Husimi Gaussian perturbation of one stream seeded by
- *   `seed` (sample_quantum_perturbation, ics.rs:434-648).  MSM_POISSON is
- *   rejected: the reference draws it from a non-reproducible thread RNG. */
+ *   `seed` (sample_quantum_perturbation, ics.rs:434-648).  MSM_POISSON
+ *   (ics.rs:495-558) draws the per-cell counts from the stream's own seeded
+ *   Philox sequence; the reference uses a non-reproducible thread RNG there. */
 int32_t msm_set_psi(msm_ctx* ctx, int32_t stream, const void* re, const void* im);
 int32_t msm_copy_psi(msm_ctx* ctx, int32_t dst_stream, int32_t src_stream);
 int32_t msm_sample(msm_ctx* ctx, int32_t stream, int32_t scheme, uint64_t seed);

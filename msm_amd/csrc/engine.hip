@@ -1379,6 +1379,63 @@ __global__ void k_sample(cplx* __restrict__ psi, size_t n, unsigned long long se
     }
 }
 
+// Poisson resampling (sample_quantum_perturbation, ics.rs:495-558): count ~ Poisson(|psi|^2 dV n) per cell,
+// psi <- sqrt(count / n) e^{i arg psi} / sqrt(dV).  The reference draws from a thread-local host RNG
+// that cannot be reproduced; here element e draws from its own Philox4x32-10 stream, counter
+// (e_lo, e_hi, j, 1), key = seed: Knuth's product method below lambda = 10, Hoermann's PTRS
+// transformed rejection above.
+__device__ __forceinline__ void philox_u2(size_t e, unsigned j, unsigned lane, unsigned long long seed, double* u1, double* u2) {
+    unsigned r[4];
+    philox4x32_10((unsigned)(e & 0xffffffffu), (unsigned)(e >> 32), j, lane, (unsigned)(seed & 0xffffffffu),
+                  (unsigned)(seed >> 32), r);
+    const unsigned long long b1 = (((unsigned long long)r[1] << 32) | r[0]) >> 11;
+    const unsigned long long b2 = (((unsigned long long)r[3] << 32) | r[2]) >> 11;
+    *u1 = ((double)b1 + 0.5) * 0x1.0p-53;
+    *u2 = ((double)b2 + 0.5) * 0x1.0p-53;
+}
+__global__ void k_sample_poisson(cplx* __restrict__ psi, size_t n, unsigned long long seed, double dv, double npart) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const cplx v = psi[e];
+        const double m2 = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        const double lam = (m2 * dv) * npart;
+        double k = 0.0;
+        if (lam < 10.0) {
+            const double limit = exp(-lam);
+            double p = 1.0;
+            for (unsigned j = 0; j < 64; ++j) {
+                double u1, u2;
+                philox_u2(e, j, 1u, seed, &u1, &u2);
+                p *= u1;
+                if (!(p > limit)) break;
+                k += 1.0;
+                p *= u2;
+                if (!(p > limit)) break;
+                k += 1.0;
+            }
+        } else {
+            const double slam = sqrt(lam), loglam = log(lam);
+            const double b = 0.931 + 2.53 * slam;
+            const double a = -0.059 + 0.02483 * b;
+            const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+            const double vr = 0.9277 - 3.6224 / (b - 2.0);
+            for (unsigned j = 0; j < 64; ++j) {
+                double u1, V;
+                philox_u2(e, j, 1u, seed, &u1, &V);
+                const double U = u1 - 0.5, us = 0.5 - fabs(U);
+                k = floor((2.0 * a / us + b) * U + lam + 0.43);
+                if (us >= 0.07 && V <= vr) break;
+                if (k < 0.0 || (us < 0.013 && V > us)) { k = 0.0; continue; }
+                if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - lgamma(k + 1.0)) break;
+                k = 0.0;
+            }
+        }
+        const double amp = sqrt(k / npart) / sqrt(dv);
+        const double mag = sqrt(m2);
+        const double ux = mag > 0.0 ? (double)v.x / mag : 1.0, uy = mag > 0.0 ? (double)v.y / mag : 0.0;
+        psi[e] = mk<real>((real)(amp * ux), (real)(amp * uy));
+    }
+}
+
 // sum over streams of |psi_s|^2 (double accumulation)
 __global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, double* __restrict__ out, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (size_t)gridDim.x * blockDim.x) {
@@ -2132,9 +2189,12 @@ int Engine::copy_psi(int dst, int src, std::string& err) {
 int Engine::sample(int s, int scheme, uint64_t seed, std::string& err) {
     if (int rc = check_stream(s, err)) return rc;
     if (int rc = need_real(err)) return rc;
-    if (scheme != MSM_WIGNER && scheme != MSM_HUSIMI) {
-        err = "only Wigner and Husimi sampling are reproducible (the reference's Poisson branch uses thread_rng)";
-        return MSM_ERR_INVALID;
+    if (scheme != MSM_WIGNER && scheme != MSM_HUSIMI && scheme != MSM_POISSON) { err = "unknown sampling scheme"; return MSM_ERR_INVALID; }
+    if (scheme == MSM_POISSON) {
+        k_sample_poisson<<<2048, 256, 0, stream_>>>(P_ + (size_t)s * n3_, n3_, (unsigned long long)seed,
+                                                    std::pow((double)dx_, (double)dims_), cfg_.total_mass / cfg_.particle_mass);
+        HIP_TRY(hipGetLastError());
+        return MSM_OK;
     }
     const double n = cfg_.total_mass / cfg_.particle_mass;      // ics.rs:472
     const real sqrt_n = (real)std::sqrt(n);

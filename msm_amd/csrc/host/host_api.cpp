@@ -103,7 +103,9 @@ int msmh_build_ics(const char* toml_path, int expanding, int precision, double d
                 case IcsType::SphericalTophat:
                     g = spherical_tophat<T>((T)t.axis_length, (T)dx, t.dims, t.size, t.ics.radius, t.ics.delta, t.ics.slope);
                     break;
-                default: throw std::runtime_error("ColdGaussKSpace initial conditions are not built yet");
+                case IcsType::ColdGaussKSpace:   // the k-space field; the transform to real space happens on the device
+                    g = cold_gauss_kspace_k<T>(t.ics.mean, t.ics.std, (T)dx, t.dims, t.size, t.ics.phase_seed.value_or(0));
+                    break;
             }
             std::memcpy(re, g.re.data(), g.re.size() * sizeof(T));
             std::memcpy(im, g.im.data(), g.im.size() * sizeof(T));

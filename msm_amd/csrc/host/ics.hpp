@@ -3,6 +3,7 @@
 // to msm_set_psi.  Flat index a*N^2 + b*N + c is the reference's device order.
 #pragma once
 #include <cmath>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,65 @@ Planes<T> cold_gauss(const std::vector<double>& mean, const std::vector<double>&
         for (size_t b = 0; b < n1; ++b)
             for (size_t a = 0; a < n0; ++a) g.re[(c * n1 + b) * n0 + a] = (fac[0][a] * fac[1][b]) * fac[2][c];
     normalize(g, dx, dims);
+    return g;
+}
+
+// Philox4x32-10 (Random123) on the host: the uniform stream of the k-space phases.
+inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// element e's uniform in (0,1): first 53 bits of the block with counter (e_lo, e_hi, 0, 2), key = seed
+inline double philox_uniform(uint64_t e, uint64_t seed) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), 0u, 2u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const uint64_t b = (((uint64_t)r[1] << 32) | r[0]) >> 11;
+    return ((double)b + 0.5) * 0x1.0p-53;
+}
+
+// ics.rs:282-431 up to (not including) the transform: separable Gaussians in k (get_kgrid values,
+// utils/fft.rs:100-120), every factor and the product normalised with (dk = dx, dims), times
+// exp(2 pi i u), u uniform from the Philox engine seeded with phase_seed (default 0; ArrayFire's own
+// uniform stream is not reproducible from the reference tree).  The caller finishes with the FORWARD
+// unitary transform (forward_inplace, ics.rs:425) on the device.
+template <typename T>
+Planes<T> cold_gauss_kspace_k(const std::vector<double>& mean, const std::vector<double>& std_, T dx, size_t dims, size_t size,
+                              uint64_t seed) {
+    if (mean.size() != dims) throw std::runtime_error("Cold Gauss k-Space: Mean vector provided has incorrect dimensionality");
+    if (std_.size() != dims) throw std::runtime_error("Cold Gauss k-Space: Std vector provided has incorrect dimensionality");
+    std::vector<T> k(size);
+    for (size_t i = 0; i < size; ++i) {
+        const long ii = i < size / 2 ? (long)i : (long)i - (long)size;
+        k[i] = (T)ii / ((T)size * dx);
+    }
+    std::vector<std::vector<T>> fac(3, std::vector<T>(1, (T)1));
+    for (size_t ax = 0; ax < dims; ++ax) {
+        Planes<T> g(size);
+        for (size_t i = 0; i < size; ++i)
+            g.re[i] = std::exp((T)-0.5 * std::pow((k[i] - (T)mean[ax]) / (T)std_[ax], (T)2.0));
+        normalize(g, dx, dims);
+        fac[ax] = g.re;
+    }
+    const size_t n0 = fac[0].size(), n1 = fac[1].size(), n2 = fac[2].size();  // fastest .. slowest
+    Planes<T> g(n0 * n1 * n2);
+    for (size_t c = 0; c < n2; ++c)
+        for (size_t b = 0; b < n1; ++b)
+            for (size_t a = 0; a < n0; ++a) g.re[(c * n1 + b) * n0 + a] = (fac[0][a] * fac[1][b]) * fac[2][c];
+    normalize(g, dx, dims);
+    const T twopi = (T)(2.0 * 3.14159265358979323846);
+    for (size_t e = 0; e < g.re.size(); ++e) {
+        const T ph = twopi * (T)philox_uniform((uint64_t)e, seed);
+        const T amp = g.re[e];
+        g.re[e] = amp * std::cos(ph);
+        g.im[e] = amp * std::sin(ph);
+    }
     return g;
 }
 

@@ -154,9 +154,13 @@ int run(const Args& args) {
         case IcsType::SphericalTophat:
             ics = spherical_tophat<T>((T)toml.axis_length, dx, toml.dims, N, toml.ics.radius, toml.ics.delta, toml.ics.slope);
             break;
-        case IcsType::ColdGaussKSpace: throw std::runtime_error("ColdGaussKSpace initial conditions are not built yet");
+        case IcsType::ColdGaussKSpace:
+            ics = cold_gauss_kspace_k<T>(toml.ics.mean, toml.ics.std, dx, toml.dims, N, toml.ics.phase_seed.value_or(0));
+            break;
     }
     check(ctx, msm_set_psi(ctx, 0, ics.re.data(), ics.im.data()), "msm_set_psi");
+    if (toml.ics.type == IcsType::ColdGaussKSpace)   // k space -> real space is the reference's forward_inplace (ics.rs:425)
+        check(ctx, msm_fft(ctx, 0, MSM_FORWARD), "msm_fft");
     for (int s = 1; s < ns; ++s) check(ctx, msm_copy_psi(ctx, s, 0), "msm_copy_psi");
     for (int s = 0; s < ns; ++s)
         if (streams[s].sampled) check(ctx, msm_sample(ctx, s, (int)streams[s].scheme, streams[s].seed), "msm_sample");

@@ -296,6 +296,83 @@ def complex_normals(n: int, seed: int) -> np.ndarray:
     return rad * np.cos(ang) + 1j * rad * np.sin(ang)
 
 
+def _uniform_pairs(e: np.ndarray, seed: int, j: int, lane: int):
+    """Two 53-bit uniforms in (0,1) from the Philox block with counter (e_lo, e_hi, j, lane)."""
+    ctr = np.zeros((e.size, 4), dtype=np.uint32)
+    ctr[:, 0] = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    ctr[:, 1] = (e >> np.uint64(32)).astype(np.uint32)
+    ctr[:, 2] = np.uint32(j)
+    ctr[:, 3] = np.uint32(lane)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.uint64)
+    b1 = (r[:, 0] | (r[:, 1] << np.uint64(32))) >> np.uint64(11)
+    b2 = (r[:, 2] | (r[:, 3] << np.uint64(32))) >> np.uint64(11)
+    return (b1.astype(np.float64) + 0.5) * 2.0 ** -53, (b2.astype(np.float64) + 0.5) * 2.0 ** -53
+
+
+def uniforms(n: int, seed: int) -> np.ndarray:
+    """n uniforms in (0,1): element e takes the first 53-bit uniform of Philox counter (e_lo, e_hi, 0, 2).
+    PARITY UNPINNED with respect to ArrayFire's random_uniform stream."""
+    return _uniform_pairs(np.arange(n, dtype=np.uint64), seed, 0, 2)[0]
+
+
+def poisson_counts(lam: np.ndarray, seed: int) -> np.ndarray:
+    """One Poisson(lam[e]) draw per element from the element's own Philox stream (counter
+    (e_lo, e_hi, j, 1), j = 0, 1, ...): Knuth's product method for lam < 10, Hoermann's PTRS
+    transformed rejection otherwise.  The reference draws from rand::thread_rng (ics.rs:497-520),
+    which is not reproducible; only the distribution carries over."""
+    lam = np.asarray(lam, dtype=np.float64).reshape(-1)
+    n = lam.size
+    e_all = np.arange(n, dtype=np.uint64)
+    out = np.zeros(n, dtype=np.float64)
+    small = lam < 10.0
+    # Knuth
+    idx = np.nonzero(small)[0]
+    if idx.size:
+        limit = np.exp(-lam[idx])
+        p = np.ones(idx.size)
+        k = np.zeros(idx.size)
+        live = np.ones(idx.size, dtype=bool)
+        j = 0
+        while live.any():
+            u1, u2 = _uniform_pairs(e_all[idx], seed, j, 1)
+            for u in (u1, u2):
+                p = np.where(live, p * u, p)
+                acc = live & (p > limit)
+                k = np.where(acc, k + 1, k)
+                live = acc
+            j += 1
+        out[idx] = k
+    # PTRS
+    idx = np.nonzero(~small)[0]
+    if idx.size:
+        l = lam[idx]
+        slam, loglam = np.sqrt(l), np.log(l)
+        b = 0.931 + 2.53 * slam
+        a = -0.059 + 0.02483 * b
+        invalpha = 1.1239 + 1.1328 / (b - 3.4)
+        vr = 0.9277 - 3.6224 / (b - 2.0)
+        res = np.zeros(idx.size)
+        live = np.ones(idx.size, dtype=bool)
+        j = 0
+        from scipy.special import gammaln
+        while live.any():
+            u1, u2 = _uniform_pairs(e_all[idx], seed, j, 1)
+            U = u1 - 0.5
+            V = u2
+            us = 0.5 - np.abs(U)
+            k = np.floor((2.0 * a / us + b) * U + l + 0.43)
+            fast = (us >= 0.07) & (V <= vr)
+            rejected = (k < 0) | ((us < 0.013) & (V > us))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                slow = (np.log(V) + np.log(invalpha) - np.log(a / (us * us) + b)) <= (-l + k * loglam - gammaln(k + 1.0))
+            acc = live & (fast | (~rejected & slow))
+            res = np.where(acc, k, res)
+            live = live & ~acc
+            j += 1
+        out[idx] = res
+    return out
+
+
 # ----------------------------------------------------------------------------
 # initial conditions (simulator/src/ics.rs)
 # ----------------------------------------------------------------------------
@@ -340,6 +417,34 @@ def cold_gauss(mean, std, dx, dims, size, dtype=np.float64):
     return normalize(psi, dx, dims)
 
 
+def cold_gauss_kspace_k(mean, std, dx, dims, size, seed=None, dtype=np.float64):
+    """ics.rs:282-424: separable Gaussians in k (get_kgrid values), each factor and the product
+    normalised with (dk = dx, dims), times exp(2 pi i u) with u uniform from the Philox engine seeded
+    with `seed` (default 0).  mean[0]/std[0] belong to the fastest axis."""
+    T = np.dtype(dtype).type
+    cdt = np.complex128 if dtype == np.float64 else np.complex64
+    k = get_kgrid(dx, size, dtype)
+    psi = None
+    for ax in range(dims):
+        g = np.exp(T(-0.5) * ((k - T(mean[ax])) / T(std[ax])) ** T(2.0)).astype(cdt)
+        g = normalize(g, dx, dims)
+        shape = [1] * dims
+        shape[dims - 1 - ax] = size
+        g = g.reshape(shape)
+        psi = g if psi is None else (psi * g).astype(cdt)
+    psi = np.ascontiguousarray(np.broadcast_to(psi, (size,) * dims)).astype(cdt)
+    psi = normalize(psi, dx, dims)
+    u = uniforms(size ** dims, 0 if seed is None else int(seed)).reshape(psi.shape).astype(dtype)
+    ph = T(2.0 * math.pi) * u
+    return (psi.real * np.cos(ph) + 1j * (psi.real * np.sin(ph))).astype(cdt)
+
+
+def cold_gauss_kspace(mean, std, dx, dims, size, seed=None, dtype=np.float64):
+    """ics.rs:282-431: the k-space field above, then the FORWARD unitary transform (the reference's
+    k -> x step is forward_inplace, :425)."""
+    return forward(cold_gauss_kspace_k(mean, std, dx, dims, size, seed, dtype))
+
+
 def user_specified_ics(path: str, dims: int, size: int, dtype=np.float64):
     """ics.rs:650-730: npz members real/imag, cubic, no renormalisation."""
     with np.load(path) as d:
@@ -374,8 +479,16 @@ def sample_quantum_perturbation(psi, dx, dims, total_mass, particle_mass, scheme
         div = sqrt_n * T(2.0)
     elif scheme == "Husimi":
         div = sqrt_n * T(np.sqrt(T(2.0)))
+    elif scheme == "Poisson":
+        # ics.rs:495-558: count ~ Poisson(|psi|^2 dV n), amplitude sqrt(count / n), original phase
+        lam = (np.abs(psi).astype(np.float64) ** 2 * float(T(dx)) ** dims) * n
+        a = poisson_counts(lam, seed).reshape(psi.shape)
+        amp = np.sqrt(a / n).astype(T)
+        mag = np.abs(psi)
+        unit = np.where(mag > 0, psi / np.where(mag > 0, mag, 1), 1.0).astype(psi.dtype)
+        return ((amp * unit) / sqrt_dv).astype(psi.dtype)
     else:
-        raise NotImplementedError("Poisson resampling is non-deterministic in the reference (ics.rs:497)")
+        raise ValueError(scheme)
     samples = z / div
     return ((psi_count + samples) / sqrt_dv).astype(psi.dtype)
 
@@ -629,6 +742,8 @@ def build_ics(p: SimulationParameters) -> np.ndarray:
         return user_specified_ics(ics["path"], p.dims, p.size, p.dtype)
     if kind == "ColdGauss":
         return cold_gauss(ics["mean"], ics["std"], p.dx, p.dims, p.size, p.dtype)
+    if kind == "ColdGaussKSpace":
+        return cold_gauss_kspace(ics["mean"], ics["std"], p.dx, p.dims, p.size, ics.get("phase_seed"), p.dtype)
     if kind == "SphericalTophat":
         return spherical_tophat(p.axis_length, p.dx, p.dims, p.size,
                                 ics["radius"], ics["delta"], ics["slope"], p.dtype)

@@ -190,3 +190,19 @@ def test_synthesize_flag_matches_post_processing(tmp_path):
             got = load_dump(tmp_path, "spherical-tophat-combined", k, field)
             assert rel(got, want[field]) < 1e-12, (k, field)
         assert abs(qre[k, 0, 0, 0] - want["Qx"].real) < 1e-12
+
+
+def test_cold_gauss_kspace_and_poisson_streams(tmp_path):
+    # [ics] ColdGaussKSpace with phase_seed + [sampling] Poisson: dump 0 of the mean-field run is the oracle's field
+    cfg = dict(TOPHAT, sim_name="cgk", final_sim_time=0.4, num_data_dumps=2,
+               ics=dict(type="ColdGaussKSpace", mean=[0.05, 0.0, -0.05], std=[0.1, 0.12, 0.08], phase_seed=11),
+               sampling=dict(seeds="5", scheme="Poisson"))
+    run_cli(tmp_path, cfg)
+    want0 = o.cold_gauss_kspace([0.05, 0.0, -0.05], [0.1, 0.12, 0.08], 30.0 / 16, 3, 16, 11)
+    assert rel(load_dump(tmp_path, "cgk", 0), want0) < 1e-12
+    sims = oracle_runs(dict(cfg, sampling=None) if False else {k: v for k, v in cfg.items() if k != "sampling"})
+    for k, psi in sims[-1].dumps:
+        assert rel(load_dump(tmp_path, "cgk", k), psi) < 1e-10, k
+    stream0 = load_dump(tmp_path, "cgk-stream00005", 0)
+    counts = np.abs(stream0) ** 2 * (30.0 / 16) ** 3 * 1e6        # ntot = 1e6
+    assert np.allclose(counts, np.round(counts), atol=1e-6) and abs(counts.sum() / 1e6 - 1) < 0.01

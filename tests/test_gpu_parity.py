@@ -456,6 +456,33 @@ def test_config5_shape_512_f32_expanding():
         assert st[0].n_steps == 2 and st[0].aliased == 0 and st[0].active == 1
 
 
+def test_poisson_resampling(golden_dir):
+    """Poisson scheme (ics.rs:495-558): counts from the stream's seeded Philox sequence.  Against the
+    oracle's restatement of the same sampler (a count may differ where a rejection test lands within
+    rounding of its threshold: at most a handful of cells), phases kept exactly, statistics as Poisson."""
+    N = 16
+    psi0 = o.user_specified_ics(os.path.join(golden_dir, "planeWave3d_e10_sym.npz"), 3, N)
+    for ntot in (1e10, 2e4):                        # lambda ~ 2.4e6 (rejection branch) and ~ 5 (product branch)
+        base = dict(PLANE, ntot=ntot)
+        with Evolver(size=N, n_streams=2, **base) as ev:
+            ev.set_psi(0, psi0)
+            ev.copy_psi(1, 0)
+            ev.sample(0, "Poisson", 3)
+            ev.sample(1, "Poisson", 4)
+            a, b = ev.get_psi(0), ev.get_psi(1)
+        want = o.sample_quantum_perturbation(psi0, 60.0 / N, 3, PLANE["total_mass"], PLANE["total_mass"] / ntot, "Poisson", 3)
+        same = np.isclose(a, want, rtol=1e-12, atol=1e-14 * np.abs(want).max())
+        assert same.mean() > 0.999
+        nz = np.abs(a) > 0
+        assert np.allclose(a[nz] / np.abs(a[nz]), psi0[nz] / np.abs(psi0[nz]), atol=1e-12)
+        dv = (60.0 / N) ** 3
+        counts, lam = np.abs(a) ** 2 * dv * ntot, np.abs(psi0) ** 2 * dv * ntot
+        assert np.allclose(counts, np.round(counts), atol=1e-6 * max(1.0, lam.max() * 1e-6))
+        z = (counts - lam) / np.sqrt(lam)
+        assert abs(z.mean()) < 0.1 and abs(z.var() - 1) < 0.1
+        assert not np.array_equal(a, b)
+
+
 _DENSITY_SCRIPT = r"""
 import sys
 import numpy as np

@@ -169,6 +169,24 @@ def test_cold_gauss(host, tmp_path):
     assert np.std(prof[2] / prof[2].sum()) < np.std(prof[1] / prof[1].sum())
 
 
+def test_cold_gauss_kspace_field(host, tmp_path):
+    # ics.rs:282-424: the k-space product with seeded uniform phases (before the transform to real space)
+    text = TOPHAT_TOML.split("[ics]")[0] + "[ics]\ntype = \"ColdGaussKSpace\"\nmean = [0.1, 0.0, -0.1]\nstd = [0.2, 0.3, 0.25]\nphase_seed = 7\n"
+    p = tmp_path / "t.toml"
+    p.write_text(text)
+    got = build(host, p, 16, 3, 30.0 / 16)
+    want = o.cold_gauss_kspace_k([0.1, 0.0, -0.1], [0.2, 0.3, 0.25], 30.0 / 16, 3, 16, 7)
+    assert np.max(np.abs(got - want)) <= 1e-14 * np.max(np.abs(want))
+    assert abs(np.sum(np.abs(got) ** 2) * (30.0 / 16) ** 3 - 1) < 1e-12
+    # the phases are a function of (element, seed) only
+    u = np.angle(got.reshape(-1)[:4]) / (2 * np.pi) % 1.0
+    assert np.allclose(u, o.uniforms(4, 7), atol=1e-12)
+    # default seed is 0
+    p.write_text(text.replace("phase_seed = 7\n", ""))
+    assert np.allclose(build(host, p, 16, 3, 30.0 / 16), o.cold_gauss_kspace_k([0.1, 0.0, -0.1], [0.2, 0.3, 0.25], 30.0 / 16, 3, 16, None),
+                       rtol=0, atol=1e-14)
+
+
 @pytest.mark.parametrize("compressed", [False, True])
 def test_user_specified_ics(host, tmp_path, golden_dir, compressed):
     # ics.rs:650-730; both plain np.savez (what sim.py writes) and deflated members

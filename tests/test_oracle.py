@@ -191,3 +191,20 @@ def test_expanding_golden_regenerates(golden_dir):
     assert len(sim.dumps) == int(g["n_dumps"]) == 4 and sim.parameters.n_steps == int(g["n_steps"])
     for k, psi in sim.dumps:
         assert np.allclose(psi, g[f"dump_{k}"], rtol=0, atol=1e-13)
+
+
+def test_poisson_counts_distribution():
+    # the stand-in for rand_distr::Poisson (ics.rs:519-520): mean and variance = lambda on both branches
+    for lam, n in ((0.3, 200000), (6.5, 200000), (40.0, 200000), (2.4e6, 4000)):
+        k = o.poisson_counts(np.full(n, lam), 9)
+        assert abs(k.mean() / lam - 1) < 5 / np.sqrt(n * lam) + 1e-9
+        assert abs(k.var() / lam - 1) < 0.05 + (0.1 if n < 10000 else 0)
+        assert np.all(k >= 0) and np.all(k == np.floor(k))
+    assert np.array_equal(o.poisson_counts(np.full(100, 3.0), 1), o.poisson_counts(np.full(100, 3.0), 1))
+    assert not np.array_equal(o.poisson_counts(np.full(100, 3.0), 1), o.poisson_counts(np.full(100, 3.0), 2))
+    assert np.all(o.poisson_counts(np.zeros(10), 3) == 0)
+
+
+def test_cold_gauss_kspace_norm():
+    psi = o.cold_gauss_kspace([0.1, 0.0, -0.1], [0.2, 0.3, 0.25], 30 / 16, 3, 16, 7)
+    assert abs(np.sum(np.abs(psi) ** 2) * (30 / 16) ** 3 - 1) < 1e-12
