@@ -263,6 +263,7 @@ struct PsiArgs {
     int src_local;       // 1: src is indexed by blockIdx.y (batch scratch), 0: by the global stream id
     int dst_local;
     int pair_nb;         // > 0: blockIdx.y is a PAIR index over nb streams (W passes)
+    int nlines;          // x passes: number of lines of the grid (a 1-D grid has fewer than one tile); 0 = no limit
     const cplx* tw;
     const cplx* drift;   // [n_streams][N]
     const real* phi;     // [batch][n3], local stream index
@@ -299,9 +300,11 @@ __global__ __launch_bounds__((Geom<N, AX>::THREADS)) void k_psi_pass(PsiArgs a) 
     const cplx* __restrict__ src = a.src + (size_t)si * a.n3;
     cplx* __restrict__ dst = a.dst + (size_t)di * a.n3;
 
+    // a tile past the end of a small grid (x passes of 1-D grids): its threads transform zeros and store nothing
+    const bool valid = AX != 0 || a.nlines == 0 || (int)(blockIdx.x * G::LPW + t.ln) < a.nlines;
     cplx v[E];
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = src[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
+    for (int q = 0; q < E; ++q) v[q] = valid ? src[t.base + (size_t)(t.j0 + TPL * q) * t.stride] : mk<real>(0, 0);
 
     if constexpr (LOAD == 1) {
         const cplx* __restrict__ d = a.drift + (size_t)sg * N;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__((Geom<N, AX>::THREADS)) void k_psi_pass(PsiArgs a) 
         const real kc = a.kick[sg];
         real ph[E];
 #pragma unroll
-        for (int q = 0; q < E; ++q) ph[q] = phi[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
+        for (int q = 0; q < E; ++q) ph[q] = valid ? phi[t.base + (size_t)(t.j0 + TPL * q) * t.stride] : (real)0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             real sn, cs;
@@ -323,12 +326,14 @@ __global__ __launch_bounds__((Geom<N, AX>::THREADS)) void k_psi_pass(PsiArgs a) 
 
     LineFft<real, N, SGN, AX == 0>::run(v, t.j0, line, tw);
 
+    if (valid) {
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const int pos = t.j0 + TPL * q;
-        cplx val = v[q];
-        if constexpr (STORE >= 1) val = cmul(val, a.drift[(size_t)sg * N + pos]);
-        dst[t.base + (size_t)pos * t.stride] = cscale(val, a.scale);
+        for (int q = 0; q < E; ++q) {
+            const int pos = t.j0 + TPL * q;
+            cplx val = v[q];
+            if constexpr (STORE >= 1) val = cmul(val, a.drift[(size_t)sg * N + pos]);
+            dst[t.base + (size_t)pos * t.stride] = cscale(val, a.scale);
+        }
     }
 }
 
@@ -1448,6 +1453,113 @@ __global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, dou
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pointwise operators for 1-D and 2-D grids (dims < 3).  Those grids are tiny next to the 3-D
+// ones, so their step is the reference's own sequence -- whole transforms (plain axis passes)
+// with one kernel per pointwise operator in between -- rather than the fused 3-D pipelines.
+// blockIdx.y = local stream; cell i = x + N y.
+// ---------------------------------------------------------------------------
+struct PwArgs {
+    const cplx* src;     // [.][n]
+    cplx* dst;
+    cplx* W;             // [batch][n] Poisson work grid, one stream per slot
+    real* PHI;
+    size_t n;
+    const int* active;
+    int s0, src_local, dst_local, N, dims;
+    const cplx* drift;
+    const real* ksq;
+    const real* kick;
+    real scale, mass_factor, pois_c, fourpi2, inv_n, alias_cut;
+    double* partial;     // [n_streams][ntiles]
+    int ntiles;
+};
+__device__ __forceinline__ real pw_k2(const PwArgs& a, size_t i) {
+    const int x = (int)(i % a.N), y = (int)(i / a.N);
+    real k2 = a.ksq[x];
+    if (a.dims >= 2) k2 = k2 + a.ksq[y];
+    return k2 * a.fourpi2;
+}
+// MODE 0: dst = src * D (kinetic half-step, simulation_object.rs:504-516)
+// MODE 1: dst = src * D * scale, plus this block's aliased-mass partial (:562-574, :1249-1280)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pw_drift(PwArgs a) {
+    __shared__ double red[256];
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    const cplx* __restrict__ src = a.src + (size_t)(a.src_local ? ls : sg) * a.n;
+    cplx* __restrict__ dst = a.dst + (size_t)(a.dst_local ? ls : sg) * a.n;
+    const cplx* __restrict__ d = a.drift + (size_t)sg * a.N;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % a.N), y = (int)(i / a.N);
+        cplx f = d[x];
+        if (a.dims >= 2) f = cmul(f, d[y]);
+        cplx v = cmul(src[i], f);
+        if constexpr (MODE == 1) {
+            v = cscale(v, a.scale);
+            if (pw_k2(a, i) > a.alias_cut) acc += (double)(v.x * v.x + v.y * v.y);
+        }
+        dst[i] = v;
+    }
+    if constexpr (MODE == 1) {
+        const double tot = block_sum<256>(acc, red);
+        if (threadIdx.x == 0) a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
+    }
+}
+// W = M |psi * scale|^2 (calculate_density, :1031-1063); src = psi (scale 1) or the unscaled inverse transform
+__global__ __launch_bounds__(256) void k_pw_rho(PwArgs a) {
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    const cplx* __restrict__ src = a.src + (size_t)(a.src_local ? ls : sg) * a.n;
+    cplx* __restrict__ w = a.W + (size_t)ls * a.n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const cplx v = cscale(src[i], a.scale);
+        w[i] = mk<real>(a.mass_factor * (v.x * v.x + v.y * v.y), (real)0);
+    }
+}
+// W *= -C / k^2 / N^dims, k = 0 -> 0 (:1076-1102)
+__global__ __launch_bounds__(256) void k_pw_green(PwArgs a) {
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    cplx* __restrict__ w = a.W + (size_t)ls * a.n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const real k2 = pw_k2(a, i);
+        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n;
+        w[i] = cscale(w[i], g);
+    }
+}
+// phi = Re W: per-block max|phi| (:905), optionally stored (msm_potential)
+template <int STOREPHI>
+__global__ __launch_bounds__(256) void k_pw_phi(PwArgs a) {
+    __shared__ double red[256];
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    const cplx* __restrict__ w = a.W + (size_t)ls * a.n;
+    real* __restrict__ phi = a.PHI + (size_t)ls * a.n;
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const real p = w[i].x;
+        if constexpr (STOREPHI) phi[i] = p;
+        m = nanmax(fabs((double)p), m);
+    }
+    const double tot = block_max<256>(m, red);
+    if (threadIdx.x == 0) a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
+}
+// psi = (psi * scale) * exp(i kick Re W) (:535-545), in place on dst
+__global__ __launch_bounds__(256) void k_pw_kick(PwArgs a) {
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (!a.active[sg]) return;
+    cplx* __restrict__ x = a.dst + (size_t)ls * a.n;
+    const cplx* __restrict__ w = a.W + (size_t)ls * a.n;
+    const real kc = a.kick[sg];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        real sn, cs;
+        sincos_t(kc * w[i].x, &sn, &cs);
+        x[i] = cmul(cscale(x[i], a.scale), mk<real>(cs, sn));
+    }
+}
+
 // In-situ synthesizer sums (synthesizer/src/main.rs:63-93): acc = [psi | |psi|^2 | psik | |psik|^2], each n complex
 // doubles; psik arrives unitary and is scaled to the synthesizer's un-normalised transform.
 __global__ void k_synth_acc(const cplx* __restrict__ psi, const cplx* __restrict__ psik, double2* __restrict__ acc, size_t n,
@@ -1570,7 +1682,12 @@ class Engine final : public IEngine {
     }
     template <int SGN, int LOAD, int STORE>
     void launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind);
-    void fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn, const int* active);
+    void fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn, const int* active,
+                    bool scaled = true);
+    // dims < 3
+    PwArgs pw_args(int s0, const int* act) const;
+    void lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act);
+    void lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
     PoisArgs pois_args(int s0, int nb, const int* act) const;
     // W passes after the fused/rho x pass; with_x = false leaves F_y,z-inverted W for a fused consumer
     void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
@@ -1612,6 +1729,8 @@ class Engine final : public IEngine {
     msm_stream_status* h_status_ = nullptr;
     std::vector<int> host_active_;
     bool fourier_ = false;   // P_ holds psi_k (after the first step)
+    bool lowdim_ = false;    // dims < 3: whole transforms + pointwise kernels
+    static constexpr int PW_BLOCKS = 64;   // blocks per stream of the pointwise kernels (and of their partials)
     bool two_pass_ = false;  // every 3-D transform in two passes (N = 256, double); psi_k is then kept as P[kx][ky][kz]
     cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
@@ -1669,11 +1788,13 @@ int Engine::init(std::string& err) {
     N_ = cfg_.size;
     ns_ = cfg_.n_streams;
     dims_ = cfg_.dims;
-    if (dims_ != 3) { err = "only dims = 3 is built"; return MSM_ERR_INVALID; }
+    if (dims_ < 1 || dims_ > 3) { err = "dims must be 1, 2 or 3"; return MSM_ERR_INVALID; }
+    lowdim_ = dims_ < 3;
     if (N_ < 2 || N_ > 512 || (N_ & (N_ - 1))) { err = "size must be a power of two in [2, 512]"; return MSM_ERR_INVALID; }
     if (ns_ < 1) { err = "n_streams must be >= 1"; return MSM_ERR_INVALID; }
     if (cfg_.num_data_dumps == 0) { err = "num_data_dumps must be >= 1"; return MSM_ERR_INVALID; }
-    n3_ = (size_t)N_ * N_ * N_;
+    n3_ = 1;
+    for (int d = 0; d < dims_; ++d) n3_ *= (size_t)N_;   // cells per grid (N^dims)
 
     HIP_TRY(hipSetDevice(cfg_.device));
     if (cfg_.hip_stream) {
@@ -1689,7 +1810,7 @@ int Engine::init(std::string& err) {
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
     if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
-    if (N_ == tp::N && sizeof(real) == 8 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
+    if (N_ == tp::N && sizeof(real) == 8 && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
     const real L = (real)cfg_.axis_length;
@@ -1711,7 +1832,7 @@ int Engine::init(std::string& err) {
     }
     const real fourpi2 = std::pow((real)(2.0 * M_PI), (real)2.0);  // utils/fft.rs:154-160
     const real km = ksq[N_ / 2];
-    c_.k2max = ((km + km) + km) * fourpi2;
+    c_.k2max = (dims_ == 3 ? ((km + km) + km) : dims_ == 2 ? (km + km) : km) * fourpi2;   // max of spec_grid, summed in axis order
     c_.cfl = (real)cfg_.cfl;
     c_.box = box;
     c_.hbar = hbar;
@@ -1736,17 +1857,17 @@ int Engine::init(std::string& err) {
         c_.pois_c = (real)(-pois_const);
         kinetic_dt_ = c_.cfl * (real)2.0 * box / std::sqrt(c_.k2max) / hbar;
     }
-    c_.inv_n3 = (real)(1.0 / ((double)N_ * N_ * N_));
+    c_.inv_n3 = (real)(1.0 / (double)n3_);
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
-    two_pass_ = (N_ == tp::N) && sizeof(real) == 8;
+    two_pass_ = (N_ == tp::N) && sizeof(real) == 8 && dims_ == 3;
     if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;   // 0: the generic three-pass engine
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         tiles_x_ = (int)(n3_ / N / Geom<N, 0>::LPW);
         tiles_z_ = (int)(n3_ / N / Geom<N, 2>::LPW);
-        ntiles_ = std::max(tiles_x_, tiles_z_);
+        ntiles_ = std::max(std::max(tiles_x_, tiles_z_), PW_BLOCKS);
     });
 
     // ---- device memory
@@ -1759,7 +1880,7 @@ int Engine::init(std::string& err) {
     const int pairs = (batch_ + 1) / 2;
     HIP_TRY(dmalloc((void**)&P_, grid_bytes * ns_));
     HIP_TRY(dmalloc((void**)&X_, grid_bytes * (size_t)(2 * pairs)));
-    HIP_TRY(dmalloc((void**)&W_, grid_bytes * pairs));
+    HIP_TRY(dmalloc((void**)&W_, grid_bytes * (lowdim_ ? 2 * pairs : pairs)));   // dims < 3: one slot per stream
     HIP_TRY(dmalloc((void**)&stage_, grid_bytes));
     HIP_TRY(dmalloc((void**)&PHI_, n3_ * sizeof(real) * (size_t)(2 * pairs)));
     HIP_TRY(dmalloc((void**)&partial_, sizeof(double) * (size_t)ns_ * ntiles_));
@@ -1830,13 +1951,16 @@ void Engine::publish(bool fresh_max) {
 }
 
 template <int SGN, int LOAD, int STORE>
-void Engine::launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind) {
+void Engine::launch_psi(int ax, const PsiArgs& a0, int nblk_y, int kind) {
+    PsiArgs a = a0;
+    const size_t lines = n3_ / (size_t)N_;
+    a.nlines = (int)std::min<size_t>(lines, (size_t)1 << 30);
     timed(kind, [&] {
         dispatch_n(N_, [&](auto nc) {
             constexpr int N = decltype(nc)::value;
             using G0 = Geom<N, 0>;
             using GS = Geom<N, 1>;
-            const dim3 grid0((unsigned)(n3_ / N / G0::LPW), (unsigned)nblk_y), gridS((unsigned)(n3_ / N / GS::LPW), (unsigned)nblk_y);
+            const dim3 grid0((unsigned)((lines + G0::LPW - 1) / G0::LPW), (unsigned)nblk_y), gridS((unsigned)(lines / GS::LPW), (unsigned)nblk_y);
             if (ax == 0) k_psi_pass<N, SGN, 0, LOAD, STORE><<<grid0, dim3(G0::THREADS), 0, stream_>>>(a);
             else if (ax == 1) k_psi_pass<N, SGN, 1, LOAD, STORE><<<gridS, dim3(GS::THREADS), 0, stream_>>>(a);
             else k_psi_pass<N, SGN, 2, LOAD, STORE><<<gridS, dim3(GS::THREADS), 0, stream_>>>(a);
@@ -1844,24 +1968,18 @@ void Engine::launch_psi(int ax, const PsiArgs& a, int nblk_y, int kind) {
     });
 }
 
-// unitary 3-D transform without pointwise work: first pass src -> dst, rest in place on dst
+// unitary transform over all dims_ axes without pointwise work: first pass src -> dst, rest in place on dst
 void Engine::fft3_plain(const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, int sgn,
-                        const int* active) {
+                        const int* active, bool scaled) {
     PsiArgs a{};
     a.n3 = n3_; a.active = active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.scale = (real)1;
     a.src = src; a.dst = dst; a.src_local = src_local; a.dst_local = dst_local;
-    if (sgn < 0) {
-        launch_psi<-1, 0, 0>(0, a, n, PK_PLAIN);
+    for (int i = 0; i < dims_; ++i) {
+        const int ax = sgn < 0 ? i : dims_ - 1 - i;
+        if (i == dims_ - 1 && scaled) a.scale = c_.unit_scale;
+        if (sgn < 0) launch_psi<-1, 0, 0>(ax, a, n, PK_PLAIN);
+        else launch_psi<+1, 0, 0>(ax, a, n, PK_PLAIN);
         a.src = dst; a.src_local = dst_local;
-        launch_psi<-1, 0, 0>(1, a, n, PK_PLAIN);
-        a.scale = c_.unit_scale;
-        launch_psi<-1, 0, 0>(2, a, n, PK_PLAIN);
-    } else {
-        launch_psi<+1, 0, 0>(2, a, n, PK_PLAIN);
-        a.src = dst; a.src_local = dst_local;
-        launch_psi<+1, 0, 0>(1, a, n, PK_PLAIN);
-        a.scale = c_.unit_scale;
-        launch_psi<+1, 0, 0>(0, a, n, PK_PLAIN);
     }
 }
 
@@ -1959,9 +2077,61 @@ void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst
     }
 }
 
+PwArgs Engine::pw_args(int s0, const int* act) const {
+    PwArgs a{};
+    a.W = W_; a.PHI = PHI_; a.n = n3_; a.active = act; a.s0 = s0; a.N = N_; a.dims = dims_; a.drift = st_.drift; a.ksq = ksq_;
+    a.kick = st_.kick; a.scale = (real)1; a.mass_factor = c_.mass_factor; a.pois_c = c_.pois_c; a.fourpi2 = c_.fourpi2;
+    a.inv_n = c_.inv_n3; a.alias_cut = c_.alias_cut; a.partial = partial_; a.ntiles = ntiles_;
+    return a;
+}
+
+// dims < 3: calculate_potential (simulation_object.rs:1066-1110) as the reference spells it: density, transform,
+// Green's multiply, transform back; max|phi| per stream; W (one slot per stream) is left holding phi in its real part.
+void Engine::lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act) {
+    PwArgs a = pw_args(s0, act);
+    a.src = psi; a.src_local = local ? 1 : 0; a.scale = psi_scale;
+    const dim3 grid(PW_BLOCKS, (unsigned)nb), block(256);
+    k_pw_rho<<<grid, block, 0, stream_>>>(a);
+    fft3_plain(W_, true, W_, true, s0, nb, -1, act, false);
+    k_pw_green<<<grid, block, 0, stream_>>>(a);
+    fft3_plain(W_, true, W_, true, s0, nb, +1, act, false);
+    if (store_phi) k_pw_phi<1><<<grid, block, 0, stream_>>>(a);
+    else k_pw_phi<0><<<grid, block, 0, stream_>>>(a);
+    k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, PW_BLOCKS, s0, act);
+    if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
+}
+
+// dims < 3: the rest of update (:504-635) with whole transforms and one kernel per pointwise operator
+void Engine::lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau) {
+    const dim3 grid(PW_BLOCKS, (unsigned)nb), block(256);
+    PwArgs a = pw_args(s0, st_.active);
+    // psi = F^-1[ D psi_k ]
+    a.src = P_; a.src_local = 0; a.dst = X_; a.dst_local = 1;
+    k_pw_drift<0><<<grid, block, 0, stream_>>>(a);
+    fft3_plain(X_, true, X_, true, s0, nb, +1, st_.active);
+    // phi at the half-drifted psi, kick
+    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.active);
+    a.dst = X_; a.scale = (real)1;
+    k_pw_kick<<<grid, block, 0, stream_>>>(a);
+    // psi_k = D F[psi], aliased mass
+    fft3_plain(X_, true, X_, true, s0, nb, -1, st_.active);
+    a.src = X_; a.src_local = 1; a.dst = P_; a.dst_local = 0; a.scale = (real)1;
+    k_pw_drift<1><<<grid, block, 0, stream_>>>(a);
+    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, PW_BLOCKS, s0, st_.active);
+    k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+    // potential of psi(t + dt) for the next timestep (:497)
+    fft3_plain(P_, false, X_, true, s0, nb, +1, st_.active);
+    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.active);
+}
+
 // Before the first step P_ holds psi: size the first timestep from it (simulation_object.rs:497)
 // and move the state to Fourier space (psi_k = F psi, :477-479).
 void Engine::first_step_init(int s0, int nb) {
+    if (lowdim_) {
+        lowdim_poisson(P_, false, (real)1, s0, nb, false, st_.active);
+        fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
+        return;
+    }
     poisson_from_psi(P_, false, s0, nb, false, true, st_.active);
     if (two_pass_) {
         psi_a(-1, P_, false, X_, true, s0, nb, st_.active);
@@ -1984,6 +2154,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     a.phi = PHI_; a.kick = st_.kick; a.scale = (real)1;
     PoisArgs p = pois_args(s0, nb, st_.active);
 
+    if (lowdim_) { lowdim_step_back(s0, nb, nt, ntau, stau); return; }
     if (two_pass_) {
         if constexpr (sizeof(real) == 8) {
             const dim3 gridA(tp::A_TILES), gridAp(tp::A_TILES, (unsigned)((nb + 1) / 2)), blockA(tp::A_THREADS);
@@ -2138,7 +2309,14 @@ int Engine::potential(int first, int count, std::string& err) {
     if (first < 0 || count < 1 || first + count > ns_) { err = "stream range out of bounds"; return MSM_ERR_INVALID; }
     if (count > 2 * ((batch_ + 1) / 2)) { err = "count exceeds the batch size"; return MSM_ERR_INVALID; }
     if (in_step_) { err = "msm_potential inside an open msm_step_begin"; return MSM_ERR_STATE; }
-    if (fourier_ && two_pass_) {
+    if (lowdim_) {
+        if (fourier_) {
+            fft3_plain(P_, false, X_, true, first, count, +1, nullptr);
+            lowdim_poisson(X_, true, (real)1, first, count, true, all_active_);
+        } else {
+            lowdim_poisson(P_, false, (real)1, first, count, true, all_active_);
+        }
+    } else if (fourier_ && two_pass_) {
         psi_b(PB_INV, false, first, count, nullptr, PK_PLAIN);
         if constexpr (sizeof(real) == 8) {
             const PoisArgs p = pois_args(first, count, all_active_);

@@ -206,3 +206,23 @@ def test_cold_gauss_kspace_and_poisson_streams(tmp_path):
     stream0 = load_dump(tmp_path, "cgk-stream00005", 0)
     counts = np.abs(stream0) ** 2 * (30.0 / 16) ** 3 * 1e6        # ntot = 1e6
     assert np.allclose(counts, np.round(counts), atol=1e-6) and abs(counts.sum() / 1e6 - 1) < 0.01
+
+
+@pytest.mark.parametrize("dims,size,flags", [(1, 64, ()), (2, 32, ()), (2, 32, ("--expanding",))])
+def test_one_and_two_dimensional_runs(tmp_path, dims, size, flags):
+    # dims = 1, 2 (examples/repro.toml is a 1-D run): dump shapes (N,1,1,1) / (N,N,1,1) (simulation_object.rs:1149-1160)
+    cfg = dict(TOPHAT, sim_name=f"low{dims}", dims=dims, size=size, final_sim_time=0.3, num_data_dumps=3,
+               sampling=dict(seeds="4", scheme="Wigner"))
+    if flags:
+        cfg["cosmology"] = dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01)
+    run_cli(tmp_path, cfg, *flags)
+    sims = oracle_runs(cfg, expanding=bool(flags))
+    assert [s.parameters.sim_name for s in sims] == [f"low{dims}-stream00004", f"low{dims}"]
+    for sim in sims:
+        assert len(sim.dumps) == 4
+        for k, psi in sim.dumps:
+            base = tmp_path / "sim-data" / sim.parameters.sim_name / f"psi_{k:05d}"
+            re, im = np.load(open(str(base) + "_real", "rb")), np.load(open(str(base) + "_imag", "rb"))
+            assert re.shape == (size,) * dims + (1,) * (4 - dims)
+            got = (re + 1j * im).reshape((size,) * dims)
+            assert rel(got, psi) < 1e-11, (sim.parameters.sim_name, k)
