@@ -277,14 +277,14 @@ def test_sampling_matches_oracle_spec(scheme, golden_dir):
         assert np.max(np.abs(got - want)) < 1e-12 * noise + 1e-15 * np.max(np.abs(psi0))
         assert np.array_equal(ev.get_psi(0), psi0)
         with pytest.raises(MsmError):
-            ev.sample(1, "Poisson", 1)
+            ev._check(ev._lib.msm_sample(ev._ctx, 1, 7, 1), "msm_sample")    # unknown scheme code
 
 
 def test_error_conventions():
     with pytest.raises(MsmError):
         Evolver(size=24, n_streams=1, **TOPHAT)          # not a power of two
     with pytest.raises(MsmError):
-        Evolver(size=16, n_streams=1, dims=2, **TOPHAT)  # only 3-D is built
+        Evolver(size=16, n_streams=1, dims=4, **TOPHAT)  # dims is 1, 2 or 3
     with Evolver(size=8, n_streams=2, **TOPHAT) as ev:
         with pytest.raises(MsmError):
             ev.set_psi(5, np.zeros((8, 8, 8), complex))
