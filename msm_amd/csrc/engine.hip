@@ -857,6 +857,46 @@ __global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
     }
 }
 
+// max|phi| only (the potential that sizes the next timestep, simulation_object.rs:497,905): one workgroup
+// owns a tile for all pairs of the batch and fetches the next pair's tile while it transforms the
+// current one (straight-line body, stream flags in LDS: see k_invx_rho3).
+__global__ __launch_bounds__(tp::A_THREADS) void k_phi_max3(PoisArgs a) {
+    constexpr int N = tp::N, E = 16;
+    __shared__ cplx lds[tp::A_LDS];
+    __shared__ double red[32];
+    __shared__ int act_lds[tp::MAX_BATCH + 2];
+    const TileA t(blockIdx.x, threadIdx.x, lds);
+    cplx* tw = lds + 2 * tp::A_HALF;
+    for (int i = threadIdx.x; i < tp::MAX_BATCH + 2; i += tp::A_THREADS) act_lds[i] = (i < a.nb) ? a.active[a.s0 + i] : 0;
+    a_load_twiddles(tw, a.tw);   // barrier inside
+    const int pairs = (a.nb + 1) / 2;
+    cplx va[E], vb[E];
+    a_fetch_T(va, t, a.W, 0);
+    auto one = [&](cplx (&v)[E], int p) {
+        const bool act_a = act_lds[2 * p] != 0, act_b = act_lds[2 * p + 1] != 0;
+        a_cols_to_lines(v, t, lds);
+        LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
+        double ma = 0.0, mb = 0.0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            ma = nanmax(fabs((double)v[q].x), ma);
+            mb = nanmax(fabs((double)v[q].y), mb);
+        }
+        block_max2<tp::A_THREADS>(ma, mb, red);   // its barrier also separates this exchange from the next column writes
+        if (threadIdx.x == 0) {
+            if (act_a) a.partial[(size_t)(a.s0 + 2 * p) * a.ntiles + blockIdx.x] = ma;
+            if (act_b) a.partial[(size_t)(a.s0 + 2 * p + 1) * a.ntiles + blockIdx.x] = mb;
+        }
+        lds_barrier();   // red[] is reused by the next pair
+    };
+    for (int p = 0; p < pairs; p += 2) {
+        a_fetch_T(vb, t, a.W, (size_t)min(p + 1, pairs - 1) * a.n3);
+        one(va, p);
+        a_fetch_T(va, t, a.W, (size_t)min(p + 2, pairs - 1) * a.n3);
+        if (p + 1 < pairs) one(vb, p + 1);
+    }
+}
+
 // Pass-B role changes through one real LDS plane (32 padded z lines).
 //   column role: thread = (z = tid >> 1, kx bit 0 = tid & 1), holds the 16 values b (or b')
 //   line role:   thread = (j0 = tid & 15, line L = tid >> 4 = 2 b' + kx bit 0), holds z = j0 + 16 q
@@ -2005,7 +2045,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
             if (with_x) timed(PK_PHI_X, [&] {
                 if (store_phi && track_max) k_phi_out2<1, 1><<<grid, block, 0, stream_>>>(p);
                 else if (store_phi) k_phi_out2<1, 0><<<grid, block, 0, stream_>>>(p);
-                else k_phi_out2<0, 1><<<grid, block, 0, stream_>>>(p);
+                else k_phi_max3<<<dim3(tp::A_TILES), block, 0, stream_>>>(p);
             });
         }
         if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::A_TILES, s0, act);
