@@ -156,6 +156,20 @@ int32_t msm_get_psi(msm_ctx* ctx, int32_t stream, void* re, void* im);
 int32_t msm_get_psik(msm_ctx* ctx, int32_t stream, void* re, void* im);
 int32_t msm_get_potential(msm_ctx* ctx, int32_t stream, void* phi);
 
+/* Dump pipeline.  msm_get_psi_async forms the planes on the compute stream and copies them out
+ * on a second stream (one of four staging grids per context); the call returns at once and the
+ * steps that follow overlap the transfer.  `re`/`im` should be pinned (msm_host_alloc) for the copy
+ * to be asynchronous; they are complete after msm_download_wait(ticket), which may be called from
+ * another thread (the dump writers of utils/io.rs:58-85).
+ * msm_set_clock: restart -- before the first step, place a stream at (time, tau) with
+ * `current_dumps` dumps already written, e.g. after msm_set_psi from its last dump.  The reference
+ * has no counterpart: its dumps are write-only (simulation_object.rs:627,915 are TODOs). */
+int32_t msm_get_psi_async(msm_ctx* ctx, int32_t stream, void* re, void* im, int32_t* ticket);
+int32_t msm_download_wait(msm_ctx* ctx, int32_t ticket);
+int32_t msm_host_alloc(size_t bytes, void** out);
+int32_t msm_host_free(void* p);
+int32_t msm_set_clock(msm_ctx* ctx, int32_t stream, double time, double tau, int32_t current_dumps);
+
 /* sum over this context's streams of |psi_s|^2 into a DEVICE buffer of N^dims
  * doubles (caller-owned; e.g. a torch tensor that is then all-reduced over
  * RCCL).  In-situ form of the synthesizer's psi2 accumulation

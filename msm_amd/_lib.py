@@ -66,6 +66,11 @@ SYMBOLS = {
     "msm_get_potential": (C.c_int32, [_P, C.c_int32, _P]),
     "msm_density_sum": (C.c_int32, [_P, _P]),
     "msm_step_density": (C.c_int32, [_P, _P]),
+    "msm_get_psi_async": (C.c_int32, [_P, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
+    "msm_download_wait": (C.c_int32, [_P, C.c_int32]),
+    "msm_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(_P)]),
+    "msm_host_free": (C.c_int32, [_P]),
+    "msm_set_clock": (C.c_int32, [_P, C.c_int32, C.c_double, C.c_double, C.c_int32]),
     "msm_synth_accumulate": (C.c_int32, [_P, C.c_int32, C.c_int32]),
     "msm_synth_device": (C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "msm_synth_set_count": (C.c_int32, [_P, C.c_int32, C.c_int64]),

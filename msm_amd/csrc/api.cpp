@@ -4,6 +4,8 @@
 #include <new>
 #include <string>
 
+#include <hip/hip_runtime.h>
+
 #include "engine.hpp"
 
 struct msm_ctx {
@@ -123,6 +125,27 @@ int32_t msm_get_psik(msm_ctx* ctx, int32_t stream, void* re, void* im) {
     MSM_CHECK_CTX(ctx);
     return ctx->eng->get_psi(stream, re, im, true, ctx->err);
 }
+int32_t msm_get_psi_async(msm_ctx* ctx, int32_t stream, void* re, void* im, int32_t* ticket) {
+    MSM_CHECK_CTX(ctx);
+    int t = -1;
+    const int rc = ctx->eng->get_psi_async(stream, re, im, &t, ctx->err);
+    if (ticket) *ticket = t;
+    return rc;
+}
+int32_t msm_download_wait(msm_ctx* ctx, int32_t ticket) {
+    MSM_CHECK_CTX(ctx);
+    std::string err;   // may be called from a writer thread while the owner thread uses ctx->err
+    return ctx->eng->download_wait(ticket, err);
+}
+int32_t msm_set_clock(msm_ctx* ctx, int32_t stream, double time, double tau, int32_t current_dumps) {
+    MSM_CHECK_CTX(ctx);
+    return ctx->eng->set_clock(stream, time, tau, current_dumps, ctx->err);
+}
+int32_t msm_host_alloc(size_t bytes, void** out) {
+    if (!out) return MSM_ERR_INVALID;
+    return hipHostMalloc(out, bytes) == hipSuccess ? MSM_OK : MSM_ERR_NOMEM;
+}
+int32_t msm_host_free(void* p) { return hipHostFree(p) == hipSuccess ? MSM_OK : MSM_ERR_HIP; }
 int32_t msm_get_potential(msm_ctx* ctx, int32_t stream, void* phi) {
     MSM_CHECK_CTX(ctx);
     return ctx->eng->get_potential(stream, phi, ctx->err);

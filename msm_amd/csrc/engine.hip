@@ -1690,6 +1690,9 @@ class Engine final : public IEngine {
     int sync(std::string& err) override;
     int get_status(msm_stream_status* out, int n, std::string& err) override;
     int get_psi(int s, void* re, void* im, bool kspace, std::string& err) override;
+    int get_psi_async(int s, void* re, void* im, int* ticket, std::string& err) override;
+    int download_wait(int ticket, std::string& err) override;
+    int set_clock(int s, double time, double tau, int current_dumps, std::string& err) override;
     int get_potential(int s, void* phi, std::string& err) override;
     int density_sum(void* dev_out, std::string& err) override;
     int step_density(void* dev_out, std::string& err) override;
@@ -1776,6 +1779,12 @@ class Engine final : public IEngine {
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
+    int planes_of(int s, bool kspace, real* stage, std::string& err);
+    static constexpr int DL_SLOTS = 4;
+    cplx* dl_stage_[DL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t dl_ready_[DL_SLOTS] = {}, dl_done_[DL_SLOTS] = {};
+    hipStream_t copy_stream_ = nullptr;
+    int dl_next_ = 0;
     struct SynthSlot { double2* sums = nullptr; long long count = 0; };
     std::vector<SynthSlot> synth_;
     int synth_check(int slot, std::string& err) const {
@@ -1807,6 +1816,16 @@ class Engine final : public IEngine {
 };
 
 void Engine::release() {
+    if (copy_stream_) {
+        (void)hipStreamSynchronize(copy_stream_);
+        for (int i = 0; i < DL_SLOTS; ++i) {
+            if (dl_stage_[i]) (void)hipFree(dl_stage_[i]);
+            if (dl_ready_[i]) (void)hipEventDestroy(dl_ready_[i]);
+            if (dl_done_[i]) (void)hipEventDestroy(dl_done_[i]);
+        }
+        (void)hipStreamDestroy(copy_stream_);
+        copy_stream_ = nullptr;
+    }
     for (auto& sl : synth_) if (sl.sums) (void)hipFree(sl.sums);
     synth_.clear();
     for (void* p : allocs_) (void)hipFree(p);
@@ -2423,9 +2442,9 @@ int Engine::sample(int s, int scheme, uint64_t seed, std::string& err) {
     return MSM_OK;
 }
 
-int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
+// psi (or psi_k in the reference's element order) of stream s as two real planes in `stage`, on the compute stream
+int Engine::planes_of(int s, bool kspace, real* stage, std::string& err) {
     if (int rc = check_stream(s, err)) return rc;
-    if (!re || !im) { err = "null plane"; return MSM_ERR_INVALID; }
     if (in_step_) { err = "download inside an open msm_step_begin"; return MSM_ERR_STATE; }
     if (kspace && !fourier_) { err = "psi_k is only defined after the first step"; return MSM_ERR_STATE; }
     const cplx* src = P_ + (size_t)s * n3_;
@@ -2444,10 +2463,70 @@ int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
         k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(src, X_, N_);
         src = X_;
     }
-    real* stage = (real*)stage_;   // two real planes fit one complex grid
     k_split<<<2048, 256, 0, stream_>>>(src, stage, stage + n3_, n3_);
+    HIP_TRY(hipGetLastError());
+    return MSM_OK;
+}
+
+int Engine::get_psi(int s, void* re, void* im, bool kspace, std::string& err) {
+    if (!re || !im) { err = "null plane"; return MSM_ERR_INVALID; }
+    real* stage = (real*)stage_;   // two real planes fit one complex grid
+    if (int rc = planes_of(s, kspace, stage, err)) return rc;
     HIP_TRY(hipMemcpyAsync(re, stage, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(im, stage + n3_, sizeof(real) * n3_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return MSM_OK;
+}
+
+// Asynchronous download: the planes are formed on the compute stream into one of DL_SLOTS staging grids and
+// copied out on a second stream, so that the steps that follow overlap the PCIe transfer (pinned host
+// buffers) and the caller's file writers.
+int Engine::get_psi_async(int s, void* re, void* im, int* ticket, std::string& err) {
+    if (!re || !im || !ticket) { err = "null plane or ticket"; return MSM_ERR_INVALID; }
+    if (!copy_stream_) {
+        HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        for (int i = 0; i < DL_SLOTS; ++i) {
+            HIP_TRY(hipMalloc((void**)&dl_stage_[i], sizeof(cplx) * n3_));
+            HIP_TRY(hipEventCreateWithFlags(&dl_ready_[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&dl_done_[i], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(dl_done_[i], copy_stream_));
+        }
+    }
+    const int slot = dl_next_ % DL_SLOTS;
+    HIP_TRY(hipEventSynchronize(dl_done_[slot]));   // the staging grid's previous copy has left
+    real* stage = (real*)dl_stage_[slot];
+    if (int rc = planes_of(s, false, stage, err)) return rc;
+    dl_next_ += 1;
+    HIP_TRY(hipEventRecord(dl_ready_[slot], stream_));
+    HIP_TRY(hipStreamWaitEvent(copy_stream_, dl_ready_[slot], 0));
+    HIP_TRY(hipMemcpyAsync(re, stage, sizeof(real) * n3_, hipMemcpyDeviceToHost, copy_stream_));
+    HIP_TRY(hipMemcpyAsync(im, stage + n3_, sizeof(real) * n3_, hipMemcpyDeviceToHost, copy_stream_));
+    HIP_TRY(hipEventRecord(dl_done_[slot], copy_stream_));
+    *ticket = slot;
+    return MSM_OK;
+}
+
+int Engine::download_wait(int ticket, std::string& err) {
+    if (ticket < 0 || ticket >= DL_SLOTS || !copy_stream_) { err = "bad download ticket"; return MSM_ERR_INVALID; }
+    HIP_TRY(hipEventSynchronize(dl_done_[ticket]));
+    return MSM_OK;
+}
+
+// Restart support (the reference has none; its `time` key assumes t0 = 0, simulation_object.rs:627,915): before
+// the first step, place a stream at (time, tau) with `current_dumps` dumps already written.
+int Engine::set_clock(int s, double time, double tau, int current_dumps, std::string& err) {
+    if (int rc = check_stream(s, err)) return rc;
+    if (int rc = need_real(err)) return rc;
+    if (current_dumps < 0 || current_dumps > (int)cfg_.num_data_dumps) { err = "current_dumps out of range"; return MSM_ERR_INVALID; }
+    const real t = (real)time, ta = (real)tau;
+    const int act = t < c_.tfinal ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(st_.time + s, &t, sizeof(real), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(st_.tau + s, &ta, sizeof(real), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(st_.dumps + s, &current_dumps, sizeof(int), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(st_.active + s, &act, sizeof(int), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    host_active_[s] = act;
+    publish();
     HIP_TRY(hipStreamSynchronize(stream_));
     return MSM_OK;
 }

@@ -22,6 +22,9 @@ struct IEngine {
     virtual int sync(std::string& err) = 0;
     virtual int get_status(msm_stream_status* out, int n, std::string& err) = 0;
     virtual int get_psi(int s, void* re, void* im, bool kspace, std::string& err) = 0;
+    virtual int get_psi_async(int s, void* re, void* im, int* ticket, std::string& err) = 0;
+    virtual int download_wait(int ticket, std::string& err) = 0;
+    virtual int set_clock(int s, double time, double tau, int current_dumps, std::string& err) = 0;
     virtual int get_potential(int s, void* phi, std::string& err) = 0;
     virtual int density_sum(void* dev_out, std::string& err) = 0;
     virtual int step_density(void* dev_out, std::string& err) = 0;

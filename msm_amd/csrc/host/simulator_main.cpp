@@ -4,18 +4,23 @@
 // (main.rs:43-79), this driver advances them together in one device context.
 //
 //   msm-simulator --toml <path> [-v|--verbose] [--test]
-//                 [--expanding] [--precision f64|f32] [--device N] [--batch B] [--synthesize]
+//                 [--expanding] [--precision f64|f32] [--device N] [--batch B] [--synthesize] [--resume]
 //
 // --expanding stands for the reference's cargo feature of the same name (compile-time there).
 // --synthesize also writes the msm-synthesizer's products (synthesizer/src/main.rs:63-187) for the seed
 //   streams, accumulated on the device as each stream reaches a dump: sim-data/{sim_name}-combined/.
+// --resume restarts every stream from its last complete dump under sim-data/ (the reference cannot: its dumps
+//   are write-only, simulation_object.rs:627,915); streams without dumps start from the initial conditions.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
+#include <functional>
 #include <future>
+#include <mutex>
+#include <condition_variable>
 #include <map>
 #include <string>
 #include <vector>
@@ -35,14 +40,14 @@ const char* SIM_DATA_FOLDER = "sim-data";           // simulation_object.rs:1116
 
 struct Args {
     std::string toml;
-    bool verbose = false, test = false, expanding = false, synthesize = false;
+    bool verbose = false, test = false, expanding = false, synthesize = false, resume = false;
     int precision = MSM_F64, device = 0, batch = 0;
 };
 
 [[noreturn]] void usage(const char* why) {
     std::fprintf(stderr, "error: %s\n\nUSAGE:\n    msm-simulator [OPTIONS] --toml <TOML>\n\nOPTIONS:\n"
                          "    -t, --toml <TOML>\n    -v, --verbose\n        --test\n        --expanding\n"
-                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n", why);
+                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n        --resume\n", why);
     std::exit(2);
 }
 
@@ -60,6 +65,7 @@ Args parse_args(int argc, char** argv) {
         else if (s == "--test") a.test = true;
         else if (s == "--expanding") a.expanding = true;
         else if (s == "--synthesize") a.synthesize = true;
+        else if (s == "--resume") a.resume = true;
         else if (s == "--precision") { const std::string p = val(); if (p == "f64") a.precision = MSM_F64; else if (p == "f32") a.precision = MSM_F32; else usage("--precision takes f64 or f32"); }
         else if (s == "--device") a.device = std::atoi(val().c_str());
         else if (s == "--batch") a.batch = std::atoi(val().c_str());
@@ -83,6 +89,11 @@ class DumpWriters {
         auto task = [](std::string path, std::vector<T> data, std::vector<size_t> shp) { write_npy<T>(path, data.data(), shp); };
         active_.push_back(std::async(std::launch::async, task, base + "_real", std::move(re), shape));
         active_.push_back(std::async(std::launch::async, task, base + "_imag", std::move(im), shape));
+    }
+    // a task that waits for its own data (an asynchronous download) and then writes
+    void submit_task(std::function<void()> task) {
+        while (active_.size() >= MAX_CONCURRENT_GRID_WRITES * 2) drain(false);
+        active_.push_back(std::async(std::launch::async, std::move(task)));
     }
     void drain(bool all) {
         for (size_t i = 0; i < active_.size();) {
@@ -187,15 +198,44 @@ int run(const Args& args) {
     // ---- dumps (simulation_object.rs:1113-1223)
     std::vector<size_t> shape(4, 1);
     for (size_t d = 0; d < toml.dims; ++d) shape[d] = N;
-    DumpWriters writers;
+    // pinned host buffers for the dump downloads: the copy runs on the library's second stream while the
+    // next steps execute, a writer thread waits for it and serialises the two planes (utils/io.rs:58-85)
+    struct PinnedPool {
+        std::vector<std::pair<T*, T*>> free;
+        std::mutex m;
+        std::condition_variable cv;
+    } pool;
+    const int n_pinned = 8;
+    for (int i = 0; i < n_pinned; ++i) {
+        void *a = nullptr, *b = nullptr;
+        if (msm_host_alloc(n_cells * sizeof(T), &a) != MSM_OK || msm_host_alloc(n_cells * sizeof(T), &b) != MSM_OK)
+            throw std::runtime_error("pinned host allocation failed");
+        pool.free.emplace_back((T*)a, (T*)b);
+    }
+    DumpWriters writers;   // declared after the pool: its pending tasks are joined before the pool goes away
     auto dump = [&](int s, int k) {
         const std::string dir = std::string(SIM_DATA_FOLDER) + "/" + streams[s].sim_name;
         std::filesystem::create_directories(dir);
         char name[64];
         std::snprintf(name, sizeof name, "/psi_%05d", k);
-        std::vector<T> re(n_cells), im(n_cells);
-        check(ctx, msm_get_psi(ctx, s, re.data(), im.data()), "msm_get_psi");
-        writers.submit<T>(dir + name, std::move(re), std::move(im), shape);
+        std::pair<T*, T*> buf;
+        {
+            std::unique_lock<std::mutex> lk(pool.m);
+            while (pool.free.empty()) { lk.unlock(); writers.drain(false); lk.lock(); if (pool.free.empty()) pool.cv.wait_for(lk, std::chrono::milliseconds(5)); }
+            buf = pool.free.back();
+            pool.free.pop_back();
+        }
+        int32_t ticket = -1;
+        check(ctx, msm_get_psi_async(ctx, s, buf.first, buf.second, &ticket), "msm_get_psi_async");
+        const std::string base = dir + name;
+        writers.submit_task([ctx, ticket, buf, base, shape, &pool] {
+            if (msm_download_wait(ctx, ticket) != MSM_OK) throw std::runtime_error("msm_download_wait failed");
+            auto re_done = std::async(std::launch::async, [&] { write_npy<T>(base + "_real", buf.first, shape); });
+            write_npy<T>(base + "_imag", buf.second, shape);
+            re_done.get();
+            { std::lock_guard<std::mutex> lk(pool.m); pool.free.push_back(buf); }
+            pool.cv.notify_one();
+        });
         if (toml.output_potential) {
             std::snprintf(name, sizeof name, "/potential_%05d", k);
             std::vector<T> phi(n_cells), zero(n_cells, (T)0);
@@ -227,7 +267,33 @@ int run(const Args& args) {
         qx_done[k] = 1;
         check(ctx, msm_synth_release(ctx, k), "msm_synth_release");
     };
-    for (int s = 0; s < ns; ++s) { dump(s, 0); synthesize(s, 0); }   // main.rs:61
+    // ---- restart: last complete dump of every stream (both planes present and of the right shape)
+    std::vector<int> resumed(ns, -1);
+    if (args.resume) {
+        for (int s = 0; s < ns; ++s) {
+            const std::string dir = std::string(SIM_DATA_FOLDER) + "/" + streams[s].sim_name;
+            for (int k = (int)toml.num_data_dumps; k >= 0 && resumed[s] < 0; --k) {
+                char name[64];
+                std::snprintf(name, sizeof name, "/psi_%05d", k);
+                try {
+                    Planes<T> g(0);
+                    for (int part = 0; part < 2; ++part) {
+                        const std::vector<unsigned char> raw = read_file(dir + name + (part ? "_imag" : "_real"), "no such dump");
+                        const NpyArray a = parse_npy(raw.data(), raw.size(), "dump");
+                        if (a.descr != NpyDescr<T>::value || a.fortran_order || a.count() != n_cells || a.bytes.size() < n_cells * sizeof(T))
+                            throw std::runtime_error("dump has another shape or type");
+                        std::vector<T>& dst = part ? g.im : g.re;
+                        dst.resize(n_cells);
+                        std::memcpy(dst.data(), a.bytes.data(), n_cells * sizeof(T));
+                    }
+                    check(ctx, msm_set_psi(ctx, s, g.re.data(), g.im.data()), "msm_set_psi");
+                    resumed[s] = k;
+                } catch (const std::exception&) { /* try the previous dump */ }
+            }
+            if (resumed[s] >= 0) std::printf("(%s) resuming from dump %d\n", streams[s].sim_name.c_str(), resumed[s]);
+        }
+    }
+    for (int s = 0; s < ns; ++s) if (resumed[s] < 0) { dump(s, 0); synthesize(s, 0); }   // main.rs:61
 
     // ---- expanding-box host state (simulation_object.rs:726-760, :939-990)
     std::vector<ScaleFactorSolver> solvers;
@@ -238,10 +304,17 @@ int run(const Args& args) {
         return it->second;
     };
     std::vector<T> time(ns, (T)cfg.time), tau(ns, (T)0);
+    for (int s = 0; s < ns; ++s)
+        if (resumed[s] >= 0) time[s] = (T)resumed[s] * (T)toml.final_sim_time / (T)toml.num_data_dumps;   // the snapped dump time (:628-630)
     if (args.expanding) {
         solvers.assign(ns, ScaleFactorSolver(*toml.cosmology));
-        for (int s = 0; s < ns; ++s) tau[s] = (T)tau_of((double)time[s]);
+        for (int s = 0; s < ns; ++s) {
+            if (resumed[s] > 0) solvers[s].step((double)time[s] - cfg.time);   // a(t) re-integrated from the start
+            tau[s] = (T)tau_of((double)time[s]);
+        }
     }
+    for (int s = 0; s < ns; ++s)
+        if (resumed[s] >= 0) check(ctx, msm_set_clock(ctx, s, (double)time[s], (double)tau[s], resumed[s]), "msm_set_clock");
 
     std::vector<msm_stream_status> st(ns), prev(ns);
     check(ctx, msm_get_status(ctx, prev.data(), ns), "msm_get_status");
@@ -317,6 +390,8 @@ int run(const Args& args) {
         }
     }
     writers.drain(true);
+    for (auto& b : pool.free) { msm_host_free(b.first); msm_host_free(b.second); }
+    pool.free.clear();
     msm_destroy(ctx);
     if (multi_stream)
         std::printf("Finished all streams in %lld seconds\n",

@@ -179,6 +179,34 @@ class Evolver:
     def step_density(self, device_ptr):
         self._check(self._lib.msm_step_density(self._ctx, device_ptr), "msm_step_density")
 
+    # -- dump pipeline / restart ---------------------------------------------
+    def pinned_planes(self):
+        """Two pinned host planes (re, im) for get_psi_async; released with free_pinned."""
+        out = []
+        for _ in range(2):
+            p = C.c_void_p()
+            nbytes = int(np.prod(self.shape)) * np.dtype(self.real).itemsize
+            self._check(self._lib.msm_host_alloc(nbytes, C.byref(p)), "msm_host_alloc")
+            buf = (C.c_char * nbytes).from_address(p.value)
+            arr = np.frombuffer(buf, dtype=self.real).reshape(self.shape)
+            out.append((arr, p.value))
+        return out
+
+    def free_pinned(self, planes):
+        for _, ptr in planes:
+            self._lib.msm_host_free(ptr)
+
+    def get_psi_async(self, stream: int, planes) -> int:
+        t = C.c_int32()
+        self._check(self._lib.msm_get_psi_async(self._ctx, stream, planes[0][1], planes[1][1], C.byref(t)), "msm_get_psi_async")
+        return t.value
+
+    def download_wait(self, ticket: int):
+        self._check(self._lib.msm_download_wait(self._ctx, ticket), "msm_download_wait")
+
+    def set_clock(self, stream: int, time: float, tau: float, current_dumps: int):
+        self._check(self._lib.msm_set_clock(self._ctx, stream, time, tau, current_dumps), "msm_set_clock")
+
     # -- in-situ synthesizer (synthesizer/src/main.rs:63-93,161-187) -------
     SYNTH_FIELDS = ("psi", "psi2", "psik", "psik2")
 

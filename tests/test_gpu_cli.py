@@ -226,3 +226,25 @@ def test_one_and_two_dimensional_runs(tmp_path, dims, size, flags):
             assert re.shape == (size,) * dims + (1,) * (4 - dims)
             got = (re + 1j * im).reshape((size,) * dims)
             assert rel(got, psi) < 1e-11, (sim.parameters.sim_name, k)
+
+
+def test_resume_from_last_dump(tmp_path):
+    # --resume: a run cut after dump 2 continues from that dump and reproduces the uninterrupted run's later dumps
+    # (the reference cannot restart: simulation_object.rs:627,915)
+    cfg = dict(TOPHAT, sampling=dict(seeds="1 to 2", scheme="Husimi"))
+    full = tmp_path / "full"
+    part = tmp_path / "part"
+    full.mkdir(); part.mkdir()
+    run_cli(full, cfg)
+    run_cli(part, dict(cfg, final_sim_time=cfg["final_sim_time"] * 2 / 5, num_data_dumps=2))     # same dump times 1, 2
+    names = ["spherical-tophat-stream00001", "spherical-tophat-stream00002", "spherical-tophat"]
+    for n in names:
+        for k in range(3):
+            assert rel(load_dump(part, n, k), load_dump(full, n, k)) < 1e-12
+    # drop stream 2's dump 2 imaginary plane: that stream must fall back to dump 1
+    os.remove(part / "sim-data" / names[1] / "psi_00002_imag")
+    r = run_cli(part, cfg, "--resume")
+    assert f"({names[0]}) resuming from dump 2" in r.stdout and f"({names[1]}) resuming from dump 1" in r.stdout
+    for n in names:
+        for k in range(6):
+            assert rel(load_dump(part, n, k), load_dump(full, n, k)) < 1e-11, (n, k)

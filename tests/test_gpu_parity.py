@@ -483,6 +483,42 @@ def test_poisson_resampling(golden_dir):
         assert not np.array_equal(a, b)
 
 
+def test_async_download_and_restart_clock():
+    """msm_get_psi_async into pinned planes overlaps the following steps and returns the state of the
+    moment it was issued; msm_set_clock places a fresh context at a dump boundary (restart)."""
+    N = 32
+    sim = oracle_sim(TOPHAT, N)
+    with Evolver(size=N, n_streams=2, **TOPHAT) as ev:
+        ev.set_psi(0, sim.psi)
+        ev.copy_psi(1, 0)
+        planes = [ev.pinned_planes() for _ in range(6)]
+        tickets, wants = [], []
+        for i in range(6):                     # more downloads in flight than staging grids
+            ev.update()
+            sim.update()
+            tickets.append(ev.get_psi_async(0, planes[i]))
+            wants.append(sim.psi.copy())
+        ev.update()
+        for i in range(6):
+            ev.download_wait(tickets[i])
+            assert rel_err(planes[i][0][0] + 1j * planes[i][1][0], wants[i]) < 1e-11, i
+        for p in planes:
+            ev.free_pinned(p)
+        k = ev.status()[0].current_dumps
+        psi_k, t_k = ev.get_psi(0), ev.status()[0].time
+        ev.update()
+        after = ev.get_psi(0)
+    with Evolver(size=N, n_streams=1, **TOPHAT) as ev2:
+        ev2.set_psi(0, psi_k)
+        ev2.set_clock(0, t_k, 0.0, k)
+        ev2.update()
+        st = ev2.status()[0]
+        assert st.current_dumps == k + 1 and abs(st.time / (t_k + st.dt) - 1) < 1e-12
+        assert rel_err(ev2.get_psi(0), after) < 1e-12
+        with pytest.raises(MsmError):
+            ev2.set_clock(0, 0.0, 0.0, 0)      # only before the first step
+
+
 _DENSITY_SCRIPT = r"""
 import sys
 import numpy as np
