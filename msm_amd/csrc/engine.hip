@@ -1869,7 +1869,7 @@ int Engine::init(std::string& err) {
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
     if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
-    if (N_ == tp::N && sizeof(real) == 8 && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
+    if (N_ == tp::N && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
     const real L = (real)cfg_.axis_length;
@@ -1919,7 +1919,7 @@ int Engine::init(std::string& err) {
     c_.inv_n3 = (real)(1.0 / (double)n3_);
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
-    two_pass_ = (N_ == tp::N) && sizeof(real) == 8 && dims_ == 3;
+    two_pass_ = (N_ == tp::N) && dims_ == 3;
     if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;   // 0: the generic three-pass engine
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     dispatch_n(N_, [&](auto nc) {
@@ -2058,7 +2058,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
     const int pairs = (nb + 1) / 2;
     const PoisArgs p = pois_args(s0, nb, act);
     if (two_pass_) {
-        if constexpr (sizeof(real) == 8) {
+        {
             timed(PK_POISSON_Z, [&] { k_poisson_b<<<dim3(tp::B_BLOCKS, (unsigned)pairs), dim3(tp::B_THREADS), 0, stream_>>>(p); });
             const dim3 grid(tp::A_TILES, (unsigned)pairs), block(tp::A_THREADS);
             if (with_x) timed(PK_PHI_X, [&] {
@@ -2097,8 +2097,7 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
     PoisArgs p = pois_args(s0, nb, act);
     p.X = X; p.x_local = local ? 1 : 0;
     if (two_pass_) {
-        if constexpr (sizeof(real) == 8)
-            timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+                    timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
     } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
@@ -2112,7 +2111,7 @@ void Engine::psi_b(int mode, bool drift, int s0, int n, const int* act, int kind
     PsiBArgs b{};
     b.T = X_; b.P = P_; b.n3 = n3_; b.active = act; b.s0 = s0; b.tw = tw_; b.drift = st_.drift; b.ksq = ksq_;
     b.scale = c_.unit_scale; b.alias_cut = c_.alias_cut; b.fourpi2 = c_.fourpi2; b.partial = partial_; b.ntiles = ntiles_;
-    if constexpr (sizeof(real) == 8) {
+    {
         const dim3 grid(tp::B_BLOCKS, (unsigned)n), block(tp::B_THREADS);
         timed(kind, [&] {
             if (mode == PB_FWD) k_psi_b<PB_FWD, 0><<<grid, block, 0, stream_>>>(b);
@@ -2127,7 +2126,7 @@ void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst
     PsiArgs a{};
     a.src = src; a.dst = dst; a.n3 = n3_; a.active = act; a.s0 = s0; a.src_local = src_local; a.dst_local = dst_local;
     a.tw = tw_; a.scale = c_.unit_scale;
-    if constexpr (sizeof(real) == 8) {
+    {
         const dim3 grid(tp::A_TILES, (unsigned)n), block(tp::A_THREADS);
         timed(PK_PLAIN, [&] {
             if (sgn < 0) k_psi_a<-1><<<grid, block, 0, stream_>>>(a);
@@ -2215,7 +2214,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
 
     if (lowdim_) { lowdim_step_back(s0, nb, nt, ntau, stau); return; }
     if (two_pass_) {
-        if constexpr (sizeof(real) == 8) {
+        {
             const dim3 gridA(tp::A_TILES), gridAp(tp::A_TILES, (unsigned)((nb + 1) / 2)), blockA(tp::A_THREADS);
             // psi = F^-1[ D psi_k ]: pass B with the whole drift factor, pass A fused with rho and the Poisson pass A
             psi_b(PB_INV, true, s0, nb, st_.active, PK_INV_Z);
@@ -2377,7 +2376,7 @@ int Engine::potential(int first, int count, std::string& err) {
         }
     } else if (fourier_ && two_pass_) {
         psi_b(PB_INV, false, first, count, nullptr, PK_PLAIN);
-        if constexpr (sizeof(real) == 8) {
+        {
             const PoisArgs p = pois_args(first, count, all_active_);
             timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p); });
         }

@@ -297,7 +297,7 @@ def test_error_conventions():
 
 
 # ---------------------------------------------------------------------------
-# full-size, oracle-free properties (256^3, the BASELINE grid)
+# full-size, oracle-free properties (256^3, the grid of the headline benchmark)
 # ---------------------------------------------------------------------------
 def test_full_size_properties_256():
     N = 256
@@ -370,17 +370,17 @@ def test_steps_and_potential_256_vs_cpu_port():
         sim.close()
 
 
-def _run_mode_256(mode, cosmology=None):
+def _run_mode_256(mode, cosmology=None, precision="f64"):
     """Five streams in sub-batches of four (one unpaired), stream 1 carrying grid-scale noise so that
     it aliases on the first step and sits out the rest; returns status rows and fields."""
     N = 256
     os.environ["MSM_TWO_PASS"] = str(mode)
     try:
         base = dict(TOPHAT, cfl=0.05, alias_threshold=1e-4, k2_cutoff=0.5)
-        with Evolver(size=N, n_streams=5, batch_streams=4, cosmology=cosmology, **base) as ev:
+        with Evolver(size=N, n_streams=5, batch_streams=4, cosmology=cosmology, precision=precision, **base) as ev:
             for s in range(5):
                 psi = rand_psi(N, 20 + s) * (0.5 if s == 1 else 1e-3) + 1.0
-                ev.set_psi(s, o.normalize(psi, 30.0 / N, 3))
+                ev.set_psi(s, o.normalize(psi, 30.0 / N, 3).astype(ev.cplx))
             rows = []
             for i in range(3):
                 if cosmology:
@@ -402,28 +402,30 @@ def _run_mode_256(mode, cosmology=None):
 
 @pytest.mark.parametrize("cosmology", [None, dict(omega_matter_now=1.0, omega_radiation_now=0.0, h=0.7, z0=9.0, max_dloga=0.01)],
                          ids=["static", "expanding"])
-def test_two_pass_engine_matches_three_pass_256(cosmology):
+@pytest.mark.parametrize("precision,tol,stol", [("f64", 1e-11, 1e-11), ("f32", 2e-4, 2e-5)])
+def test_two_pass_engine_matches_three_pass_256(cosmology, precision, tol, stol):
     """The 256^3 two-pass engine (blocked work-array layouts, psi_k kept transposed) against the
     plain three-passes-per-transform engine that the small-N oracle tests pin: same steps, same
     activity flags, fields equal to rounding -- with an unpaired stream and a stream that drops out."""
-    r3, psi3, psik3, phi3 = _run_mode_256(0, cosmology)
-    r2, psi2, psik2, phi2 = _run_mode_256(2, cosmology)
+    r3, psi3, psik3, phi3 = _run_mode_256(0, cosmology, precision)
+    r2, psi2, psik2, phi2 = _run_mode_256(2, cosmology, precision)
     assert [row[1][4] for row in r3] == [0, 0, 0] and r3[0][1][5] == 1       # stream 1 aliased at step 1
     for a, b in zip(r3, r2):
         for x, y in zip(a, b):
             assert x[4:] == y[4:]
-            assert abs(x[0] / y[0] - 1) < 1e-12 and abs(x[1] / y[1] - 1) < 1e-12
-            assert abs(x[2] / y[2] - 1) < 1e-11
-            assert abs(x[3] - y[3]) <= 1e-9 * max(abs(x[3]), 1e-30) + 1e-22
+            assert abs(x[0] / y[0] - 1) < stol and abs(x[1] / y[1] - 1) < stol
+            # fp32: phi of a nearly uniform density is a difference of nearly equal numbers
+            assert abs(x[2] / y[2] - 1) < (stol if precision == "f64" else 5e-3)
+            assert abs(x[3] - y[3]) <= (1e-9 if precision == "f64" else 1e-3) * max(abs(x[3]), 1e-30) + (1e-22 if precision == "f64" else 1e-12)
     for s in range(5):
-        assert rel_err(psi2[s], psi3[s]) < 1e-11
-        assert rel_err(psik2[s], psik3[s]) < 1e-11
+        assert rel_err(psi2[s], psi3[s]) < tol
+        assert rel_err(psik2[s], psik3[s]) < tol
     for s in range(4):
-        assert rel_err(phi2[s], phi3[s]) < 1e-11
+        assert rel_err(phi2[s], phi3[s]) < (tol if precision == "f64" else 1e-2)
 
 
 def test_config5_shape_512_f32_expanding():
-    """512^3 fp32, expanding box (the largest BASELINE configuration, one pair of streams): runs on the
+    """512^3 fp32, expanding box (the shape of the largest benchmark configuration, one pair of streams): runs on the
     generic three-pass engine.  Oracle-free properties: Parseval and round trip at fp32 accuracy,
     the two streams of a pair (real / imaginary lane of one Poisson solve) stay equal to fp32 rounding,
     the step conserves the norm, dt obeys the kinetic bound."""

@@ -99,7 +99,7 @@ def test_philox_known_answers():
 
 
 def test_sampling_statistics():
-    # ics.rs:560-646 and SURVEY appendix B: per-component sigma 1/(2 sqrt n) (Wigner), 1/sqrt(2 n) (Husimi)
+    # ics.rs:560-646: per-component sigma 1/(2 sqrt n) (Wigner), 1/sqrt(2 n) (Husimi)
     N, dx = 16, 0.5
     n = 1.0e4
     psi = np.full((N, N, N), 0.3 + 0.1j, dtype=np.complex128)
