@@ -193,6 +193,8 @@ def main():
                         moved_gbs=round(moved * cells_per_launch / avg_s / 1e9, 1),
                         step_alg_gbs=round(value * B_ALG_STEP / world / 1e9, 1),
                         step_frac=round(value * B_ALG_STEP / world / 1e9 / HBM_PEAK_GBS, 4),
+                        # stricter model: the four Poisson transforms counted as real-data transforms (168 B per update)
+                        step_frac_real_poisson=round(value * 168.0 / world / 1e9 / HBM_PEAK_GBS, 4),
                         per_kind_ms={k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
                         passes_per_transform=2 if two_pass else 3)
         out = {

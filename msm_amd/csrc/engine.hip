@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
     const int ls = blockIdx.y, sg = a.s0 + ls;
     if (a.active != nullptr && !a.active[sg]) return;
     if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];
+    lds_barrier();   // the z lines exchange inside their wavefront: PB_INV would otherwise reach the table with no barrier in between
     const RunB rb;
     const RolesB r(plane);
     const size_t trun = (size_t)ls * a.n3 + rb.off;
