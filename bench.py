@@ -135,12 +135,13 @@ def main():
         if use_dist:
             b = i & 1
             if work[b] is not None:
-                work[b].wait()
+                work[b].wait()                                  # the all-reduce of two steps ago ...
+                torch.cuda.current_stream().synchronize()       # ... has really finished before its buffer is reused
             ev.step_density(dens[b].data_ptr())                 # the step leaves sum_s |psi_s|^2 here
         ev.update()
-        if use_dist:
-            work[b] = allreduce_density(dist, dens[b], async_op=True)   # sum over ranks; mean = / streams
-        ev.sync()                                               # per-step status (dt, dump flags) on the host
+        ev.sync()                                               # per-step status (dt, dump flags) on the host; the
+        if use_dist:                                            # density is complete before the collective may read it
+            work[b] = allreduce_density(dist, dens[b], async_op=True)   # overlaps the next step; mean = / streams
 
     def barrier():
         ev.sync()
