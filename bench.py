@@ -58,6 +58,25 @@ KINDS_TWO_PASS = {
 }
 
 
+# pass kind -> kernel name in the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+# command at 32 streams per launch, corrected as profiles/summarize_pmc.py documents)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic_32streams.json")
+PMC_KERNEL = {"psi_inv_z": "k_psi_b<1, 1>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
+              "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_b<2, 1>", "phi_inv_x": "k_phi_max3"}
+
+
+def measured_traffic(kind, two_pass, cells_per_launch, n3):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, when the committed summary covers this
+    launch shape (two-pass engine, 32 x 256^3 cells per launch); None otherwise."""
+    if not two_pass or cells_per_launch != 32 * n3 or n3 != 256 ** 3 or kind not in PMC_KERNEL:
+        return None
+    try:
+        with open(PMC_SUMMARY) as f:
+            return int(json.load(f)[PMC_KERNEL[kind]]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(size, seconds_cap=30.0):
     """C port of the reference step (oracle/sp_cpu.c, OpenMP) on one stream of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -188,7 +207,9 @@ def main():
         avg_s = kms / kcnt / 1e3
         achieved = npass * B_ALG_PASS * cells_per_launch / avg_s / 1e9
         roofline = dict(bound="hbm", kernel=kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=moved * cells_per_launch,
+                        frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=measured_traffic(kind, two_pass, cells_per_launch, n3),   # PMC counters, or null
+                        modelled_bytes_per_launch=moved * cells_per_launch,
                         avg_launch_ms=round(kms / kcnt, 4), launches=int(kcnt),
                         alg_bytes_per_launch=npass * B_ALG_PASS * cells_per_launch,
                         moved_gbs=round(moved * cells_per_launch / avg_s / 1e9, 1),
