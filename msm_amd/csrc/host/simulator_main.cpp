@@ -5,12 +5,15 @@
 //
 //   msm-simulator --toml <path> [-v|--verbose] [--test]
 //                 [--expanding] [--precision f64|f32] [--device N] [--batch B] [--synthesize] [--resume]
+//                 [--rank R --world W]
 //
 // --expanding stands for the reference's cargo feature of the same name (compile-time there).
 // --synthesize also writes the msm-synthesizer's products (synthesizer/src/main.rs:63-187) for the seed
 //   streams, accumulated on the device as each stream reaches a dump: sim-data/{sim_name}-combined/.
 // --resume restarts every stream from its last complete dump under sim-data/ (the reference cannot: its dumps
 //   are write-only, simulation_object.rs:627,915); streams without dumps start from the initial conditions.
+// --rank R --world W: this process evolves block R of the seed list split into W blocks (one process per GPU,
+//   streams are independent: main.rs:43-79); the mean-field run goes to rank 0.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -41,13 +44,13 @@ const char* SIM_DATA_FOLDER = "sim-data";           // simulation_object.rs:1116
 struct Args {
     std::string toml;
     bool verbose = false, test = false, expanding = false, synthesize = false, resume = false;
-    int precision = MSM_F64, device = 0, batch = 0;
+    int precision = MSM_F64, device = 0, batch = 0, rank = 0, world = 1;
 };
 
 [[noreturn]] void usage(const char* why) {
     std::fprintf(stderr, "error: %s\n\nUSAGE:\n    msm-simulator [OPTIONS] --toml <TOML>\n\nOPTIONS:\n"
                          "    -t, --toml <TOML>\n    -v, --verbose\n        --test\n        --expanding\n"
-                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n        --resume\n", why);
+                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n        --resume\n        --rank <R> --world <W>\n", why);
     std::exit(2);
 }
 
@@ -66,12 +69,16 @@ Args parse_args(int argc, char** argv) {
         else if (s == "--expanding") a.expanding = true;
         else if (s == "--synthesize") a.synthesize = true;
         else if (s == "--resume") a.resume = true;
+        else if (s == "--rank") a.rank = std::atoi(val().c_str());
+        else if (s == "--world") a.world = std::atoi(val().c_str());
         else if (s == "--precision") { const std::string p = val(); if (p == "f64") a.precision = MSM_F64; else if (p == "f32") a.precision = MSM_F32; else usage("--precision takes f64 or f32"); }
         else if (s == "--device") a.device = std::atoi(val().c_str());
         else if (s == "--batch") a.batch = std::atoi(val().c_str());
         else usage(("Found argument '" + s + "' which wasn't expected").c_str());
     }
     if (a.toml.empty()) usage("The following required arguments were not provided: --toml <TOML>");
+    if (a.world < 1 || a.rank < 0 || a.rank >= a.world) usage("--rank must lie in [0, --world)");
+    if (a.world > 1 && a.synthesize) usage("--synthesize needs every stream in one process; with several GPUs use the Python driver (msm_amd.synth)");
     return a;
 }
 
@@ -115,7 +122,16 @@ template <typename T>
 int run(const Args& args) {
     const auto t_start = std::chrono::steady_clock::now();
     const TomlParameters toml = read_toml(args.toml, args.expanding);
-    const std::vector<StreamSpec> streams = simulation_iter(toml);
+    std::vector<StreamSpec> streams = simulation_iter(toml);
+    if (args.world > 1) {
+        // block partition of the seed streams (ceil(n / world) each); the trailing mean-field run stays with rank 0
+        const size_t n_seed = streams.size() - 1, per = (n_seed + args.world - 1) / args.world;
+        const size_t first = std::min(per * (size_t)args.rank, n_seed), last = std::min(first + per, n_seed);
+        std::vector<StreamSpec> mine(streams.begin() + first, streams.begin() + last);
+        if (args.rank == 0) mine.push_back(streams.back());
+        streams.swap(mine);
+        if (streams.empty()) { std::printf("rank %d of %d: no streams\n", args.rank, args.world); return 0; }
+    }
     const bool multi_stream = streams.size() - 1 > 1;   // SimulationIter::len() counts the seeds (io.rs:121-125)
     const int ns = (int)streams.size();
     double particle_mass, hbar_;

@@ -248,3 +248,18 @@ def test_resume_from_last_dump(tmp_path):
     for n in names:
         for k in range(6):
             assert rel(load_dump(part, n, k), load_dump(full, n, k)) < 1e-11, (n, k)
+
+
+def test_rank_world_partition(tmp_path):
+    # --rank/--world: block partition of the seed streams over processes, the mean-field run on rank 0
+    cfg = dict(TOPHAT, sampling=dict(seeds="1 to 3", scheme="Husimi"))
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    run_cli(one, cfg)
+    r0 = run_cli(two, cfg, "--rank", "0", "--world", "2")
+    r1 = run_cli(two, cfg, "--rank", "1", "--world", "2")
+    assert "stream00003" not in r0.stdout and "stream00001" not in r1.stdout
+    for n in ["spherical-tophat-stream00001", "spherical-tophat-stream00002", "spherical-tophat-stream00003", "spherical-tophat"]:
+        for k in range(6):
+            assert rel(load_dump(two, n, k), load_dump(one, n, k)) < 1e-12, (n, k)   # pair partners differ: rounding only
+    run_cli(two, cfg, "--rank", "2", "--world", "2", expect=2)
