@@ -146,3 +146,64 @@ def test_reduction_path_over_rccl(tmp_path):
     script.write_text(_DIST_SCRIPT)
     r = subprocess.run([sys.executable, str(script), root, str(tmp_path), str(port)], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "SYNTH_DIST_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_multi_process_driver_matches_cli(tmp_path):
+    """python -m msm_amd.run on two ranks (3 seed streams split 2 + 1, mean-field run on rank 0, gloo over the one
+    GPU of the test box): dumps equal the single-process msm-simulator's, the -combined/ products equal the
+    reference synthesizer's arithmetic on those dumps."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    toml = tmp_path / "run.toml"
+    toml.write_text("""axis_length = 30.0
+final_sim_time = 1.0
+cfl = 0.5
+num_data_dumps = 5
+total_mass = 1e11
+ntot = 1e6
+hbar_ = 0.05
+sim_name = "spherical-tophat"
+k2_cutoff = 0.95
+alias_threshold = 0.02
+dims = 3
+size = 16
+
+[ics]
+type = "SphericalTophat"
+radius = 5.0
+slope = 50.0
+delta = 100.0
+
+[sampling]
+seeds = "1 to 3"
+scheme = "Husimi"
+""")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    r = subprocess.run([os.path.join(root, "msm_amd", "bin", "msm-simulator"), "--toml", str(toml)], cwd=one, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "msm_amd.run", "--toml", str(toml), "--synthesize", "--backend", "gloo"],
+                       cwd=two, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    names = [f"spherical-tophat-stream{k:05d}" for k in (1, 2, 3)]
+    for n in names + ["spherical-tophat"]:
+        for k in range(6):
+            a = load_complex(str(two / "sim-data" / n / f"psi_{k:05d}"))
+            b = load_complex(str(one / "sim-data" / n / f"psi_{k:05d}"))
+            assert rel(a, b) < 1e-12, (n, k)
+    dv = (30.0 / 16) ** 3
+    qx = load_complex(str(two / "sim-data" / "spherical-tophat-combined" / "Qx"))
+    assert qx.shape == (6, 1, 1, 1)
+    for k in range(6):
+        want = o.reference_synthesis([load_complex(str(one / "sim-data" / n / f"psi_{k:05d}"))[..., 0] for n in names], dv)
+        for f in FIELDS:
+            got = load_complex(str(two / "sim-data" / "spherical-tophat-combined" / f"{f}_{k:05d}"))[..., 0]
+            assert rel(got, want[f]) < 1e-11, (k, f)
+        assert abs(qx[k, 0, 0, 0] - want["Qx"]) < 1e-11
