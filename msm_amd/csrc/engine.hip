@@ -996,7 +996,9 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
     const int p = blockIdx.y;
     const int sa = a.s0 + 2 * p, sb = sa + 1;
     if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
-    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];   // first read is behind the exchange barriers
+    __shared__ real kq[N];
+    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];   // first reads are behind the exchange barriers
+    else if (tid < 2 * N) kq[tid - N] = a.ksq[tid - N];
     const RunB rb;
     const RolesB r(plane);
     const size_t trun = (size_t)p * a.n3 + rb.off;
@@ -1005,10 +1007,10 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
     cplx v[16];
     b_forward(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
     const int kx = rb.kx(r), ky = rb.ky(r);
-    const real kxy = a.ksq[kx] + a.ksq[ky];   // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
+    const real kxy = kq[kx] + kq[ky];   // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const real k2 = (kxy + a.ksq[r.j0 + 16 * q]) * a.fourpi2;
+        const real k2 = (kxy + kq[r.j0 + 16 * q]) * a.fourpi2;
         const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
         v[q] = cscale(v[q], g);
     }
@@ -1042,10 +1044,17 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
     __shared__ real plane[tp::B_PLANE];
     __shared__ cplx tw[N];
     __shared__ double red[MODE == PB_MID ? tp::B_THREADS / 64 : 1];
+    constexpr bool USE_DRIFT = MODE == PB_MID || DRIFT;
+    __shared__ cplx dl[USE_DRIFT ? N : 1];      // this stream's 1-D drift factors
+    __shared__ real kq[MODE == PB_MID ? N : 1];  // k_i^2 table
     const int tid = threadIdx.x;
     const int ls = blockIdx.y, sg = a.s0 + ls;
     if (a.active != nullptr && !a.active[sg]) return;
+    // tables go to LDS up front: read from global memory in the middle of the kernel they would either expose an L2
+    // round trip behind the transform or be hoisted into sixteen live register pairs
     if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];
+    else if (USE_DRIFT && tid < 2 * N) dl[tid - N] = a.drift[(size_t)sg * N + (tid - N)];
+    else if (MODE == PB_MID && tid < 3 * N) kq[tid - 2 * N] = a.ksq[tid - 2 * N];
     lds_barrier();   // the z lines exchange inside their wavefront: PB_INV would otherwise reach the table with no barrier in between
     const RunB rb;
     const RolesB r(plane);
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
     const unsigned toff = rb.toff;
     const int kx = rb.kx(r), ky = rb.ky(r);
     cplx* __restrict__ prow = a.P + (size_t)sg * a.n3 + ((size_t)kx * N + ky) * N + r.j0;
-    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+    const cplx* d = dl;
 
     cplx v[16];
     if constexpr (MODE != PB_INV) {
@@ -1069,11 +1078,11 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
             prow[16 * q] = v[q];
         }
         if constexpr (MODE == PB_MID) {
-            const real kxy = a.ksq[kx] + a.ksq[ky];
+            const real kxy = kq[kx] + kq[ky];
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const real k2 = (kxy + a.ksq[r.j0 + 16 * q]) * a.fourpi2;
+                const real k2 = (kxy + kq[r.j0 + 16 * q]) * a.fourpi2;
                 if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
             }
 #pragma unroll
