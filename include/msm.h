@@ -49,7 +49,7 @@ typedef struct msm_config {
     int32_t struct_size;        /* = sizeof(msm_config), ABI check              */
     int32_t device;             /* HIP device ordinal (reference: set_device(0)) */
     int32_t dims;               /* 3 (1 and 2 are not built yet)                 */
-    int32_t size;               /* N, power of two in [2, 512]                   */
+    int32_t size;               /* N, even, in [2, 1024] (utils/fft.rs:105)      */
     int32_t precision;          /* msm_precision                                 */
     int32_t n_streams;          /* streams held by this context                  */
     int32_t batch_streams;      /* streams advanced per kernel launch; 0 = auto  */

@@ -15,7 +15,9 @@
 // inverse z around the second drift; inverse x + density + Poisson forward x).
 // Between steps only psi_k is kept; psi is rebuilt on demand for downloads.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1504,10 +1506,11 @@ __global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, dou
 }
 
 // ---------------------------------------------------------------------------
-// Pointwise operators for 1-D and 2-D grids (dims < 3).  Those grids are tiny next to the 3-D
-// ones, so their step is the reference's own sequence -- whole transforms (plain axis passes)
-// with one kernel per pointwise operator in between -- rather than the fused 3-D pipelines.
-// blockIdx.y = local stream; cell i = x + N y.
+// Pointwise operators of the unfused step: 1-D and 2-D grids (tiny next to the 3-D ones) and 3-D
+// grids whose edge is not a power of two up to 512 (chirp-z line transforms below).  Their step
+// is the reference's own sequence -- whole transforms (plain axis passes) with one kernel per
+// pointwise operator in between -- rather than the fused 3-D pipelines.
+// blockIdx.y = local stream; cell i = x + N y + N^2 z.
 // ---------------------------------------------------------------------------
 struct PwArgs {
     const cplx* src;     // [.][n]
@@ -1524,10 +1527,18 @@ struct PwArgs {
     double* partial;     // [n_streams][ntiles]
     int ntiles;
 };
-__device__ __forceinline__ real pw_k2(const PwArgs& a, size_t i) {
-    const int x = (int)(i % a.N), y = (int)(i / a.N);
+// cell i -> (x, y, z), x fastest; y and z are 0 on the axes a smaller grid does not have
+__device__ __forceinline__ void pw_xyz(const PwArgs& a, size_t i, int& x, int& y, int& z) {
+    const size_t r = i / a.N;
+    x = (int)(i - r * a.N);
+    z = (int)(r / a.N);
+    y = (int)(r - (size_t)z * a.N);
+}
+// spec_grid (utils/fft.rs:123-161): the axes are summed in order, then times (2 pi)^2
+__device__ __forceinline__ real pw_k2(const PwArgs& a, int x, int y, int z) {
     real k2 = a.ksq[x];
     if (a.dims >= 2) k2 = k2 + a.ksq[y];
+    if (a.dims >= 3) k2 = k2 + a.ksq[z];
     return k2 * a.fourpi2;
 }
 // MODE 0: dst = src * D (kinetic half-step, simulation_object.rs:504-516)
@@ -1542,13 +1553,15 @@ __global__ __launch_bounds__(256) void k_pw_drift(PwArgs a) {
     const cplx* __restrict__ d = a.drift + (size_t)sg * a.N;
     double acc = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % a.N), y = (int)(i / a.N);
+        int x, y, z;
+        pw_xyz(a, i, x, y, z);
         cplx f = d[x];
         if (a.dims >= 2) f = cmul(f, d[y]);
+        if (a.dims >= 3) f = cmul(f, d[z]);
         cplx v = cmul(src[i], f);
         if constexpr (MODE == 1) {
             v = cscale(v, a.scale);
-            if (pw_k2(a, i) > a.alias_cut) acc += (double)(v.x * v.x + v.y * v.y);
+            if (pw_k2(a, x, y, z) > a.alias_cut) acc += (double)(v.x * v.x + v.y * v.y);
         }
         dst[i] = v;
     }
@@ -1574,7 +1587,9 @@ __global__ __launch_bounds__(256) void k_pw_green(PwArgs a) {
     if (!a.active[sg]) return;
     cplx* __restrict__ w = a.W + (size_t)ls * a.n;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const real k2 = pw_k2(a, i);
+        int x, y, z;
+        pw_xyz(a, i, x, y, z);
+        const real k2 = pw_k2(a, x, y, z);
         const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n;
         w[i] = cscale(w[i], g);
     }
@@ -1607,6 +1622,92 @@ __global__ __launch_bounds__(256) void k_pw_kick(PwArgs a) {
         real sn, cs;
         sincos_t(kc * w[i].x, &sn, &cs);
         x[i] = cmul(cscale(x[i], a.scale), mk<real>(cs, sn));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Line transform of ANY even length N <= 1024 (the reference only asks for an even edge,
+// utils/fft.rs:105; ArrayFire transforms any length): Bluestein's chirp-z algorithm,
+//   X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / N),
+// the convolution done with power-of-two transforms of length M >= 2N - 1 held in LDS:
+// decimation in frequency forward (natural in, bit-reversed out), times the precomputed
+// spectrum of conj(c) (stored bit-reversed, 1/M folded in), decimation in time back
+// (bit-reversed in, natural out).  A workgroup owns `lpw` neighbouring lines.  The inverse
+// transform is conj(F[conj(x)]).  Unnormalised; `scale` is applied on store.
+// ---------------------------------------------------------------------------
+struct AnyArgs {
+    const cplx* src;
+    cplx* dst;
+    size_t n3;
+    const int* active;   // may be null
+    int s0, src_local, dst_local;
+    int N, M, lpw;
+    size_t stride;       // N^axis: distance between consecutive points of a line
+    const cplx* chirp;   // [N]    exp(-i pi n^2 / N)
+    const cplx* bhat;    // [M]    F_M[conj chirp, wrapped] / M in bit-reversed order
+    const cplx* twm;     // [M/2]  exp(-2 pi i k / M)
+    real scale;
+};
+template <int SGN>
+__global__ __launch_bounds__(256) void k_line_any(AnyArgs a) {
+    extern __shared__ __align__(16) unsigned char any_smem[];
+    cplx* buf = reinterpret_cast<cplx*>(any_smem);            // [lpw][M]
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (a.active != nullptr && !a.active[sg]) return;
+    const cplx* __restrict__ src = a.src + (size_t)(a.src_local ? ls : sg) * a.n3;
+    cplx* __restrict__ dst = a.dst + (size_t)(a.dst_local ? ls : sg) * a.n3;
+    const int N = a.N, M = a.M, lpw = a.lpw, tid = threadIdx.x;
+    // line l = lo + stride * hi starts at hi * stride * N + lo; the lpw lines of a workgroup share hi
+    const size_t l0 = (size_t)blockIdx.x * lpw;
+    const size_t hi = l0 / a.stride, lo = l0 - hi * a.stride;
+    const size_t base = hi * a.stride * N + lo;
+    const bool xaxis = a.stride == 1;
+
+    for (int e = tid; e < lpw * M; e += 256) {
+        int ln, j;
+        if (xaxis) { ln = e / M; j = e - ln * M; } else { j = e / lpw; ln = e - j * lpw; }
+        cplx v = mk<real>(0, 0);
+        if (j < N) {
+            v = src[base + (xaxis ? (size_t)ln * N + j : (size_t)j * a.stride + ln)];
+            if (SGN > 0) v.y = -v.y;
+            v = cmul(v, a.chirp[j]);
+        }
+        buf[ln * M + j] = v;
+    }
+    __syncthreads();
+    const int halfM = M >> 1, nbf = lpw * halfM;
+    for (int half = halfM, tstep = 1; half >= 1; half >>= 1, tstep <<= 1) {
+        for (int b = tid; b < nbf; b += 256) {
+            const int ln = b / halfM, r = b - ln * halfM;
+            const int j = r & (half - 1), g = r / half;
+            const int i0 = ln * M + g * 2 * half + j, i1 = i0 + half;
+            const cplx u = buf[i0], v = buf[i1];
+            buf[i0] = cadd(u, v);
+            buf[i1] = cmul(csub(u, v), a.twm[j * tstep]);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < lpw * M; e += 256) buf[e] = cmul(buf[e], a.bhat[e % M]);
+    __syncthreads();
+    for (int half = 1, tstep = halfM; half <= halfM; half <<= 1, tstep >>= 1) {
+        for (int b = tid; b < nbf; b += 256) {
+            const int ln = b / halfM, r = b - ln * halfM;
+            const int j = r & (half - 1), g = r / half;
+            const int i0 = ln * M + g * 2 * half + j, i1 = i0 + half;
+            cplx w = a.twm[j * tstep];
+            w.y = -w.y;
+            const cplx u = buf[i0], v = cmul(buf[i1], w);
+            buf[i0] = cadd(u, v);
+            buf[i1] = csub(u, v);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < lpw * N; e += 256) {
+        int ln, j;
+        if (xaxis) { ln = e / N; j = e - ln * N; } else { j = e / lpw; ln = e - j * lpw; }
+        cplx v = cmul(buf[ln * M + j], a.chirp[j]);
+        if (SGN > 0) v.y = -v.y;
+        dst[base + (xaxis ? (size_t)ln * N + j : (size_t)j * a.stride + ln)] = cscale(v, a.scale);
     }
 }
 
@@ -1782,8 +1883,13 @@ class Engine final : public IEngine {
     msm_stream_status* h_status_ = nullptr;
     std::vector<int> host_active_;
     bool fourier_ = false;   // P_ holds psi_k (after the first step)
-    bool lowdim_ = false;    // dims < 3: whole transforms + pointwise kernels
-    static constexpr int PW_BLOCKS = 64;   // blocks per stream of the pointwise kernels (and of their partials)
+    bool lowdim_ = false;    // dims < 3 or chirp-z lines: whole transforms + pointwise kernels
+    int pw_blocks_ = 64;     // blocks per stream of the pointwise kernels (and of their partials)
+    // chirp-z line transforms: any even N that the power-of-two line engine does not serve
+    bool anyn_ = false;
+    int any_M_ = 0, any_lpw_ = 1;
+    cplx *chirp_ = nullptr, *bhat_ = nullptr, *twm_ = nullptr;
+    template <int SGN> void launch_any(int ax, const PsiArgs& a, int nblk_y, int kind);
     bool two_pass_ = false;  // every 3-D transform in two passes (N = 256, double); psi_k is then kept as P[kx][ky][kz]
     cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
@@ -1858,8 +1964,11 @@ int Engine::init(std::string& err) {
     ns_ = cfg_.n_streams;
     dims_ = cfg_.dims;
     if (dims_ < 1 || dims_ > 3) { err = "dims must be 1, 2 or 3"; return MSM_ERR_INVALID; }
-    lowdim_ = dims_ < 3;
-    if (N_ < 2 || N_ > 512 || (N_ & (N_ - 1))) { err = "size must be a power of two in [2, 512]"; return MSM_ERR_INVALID; }
+    // get_kgrid asserts an even edge (utils/fft.rs:105); powers of two up to 512 have register line transforms
+    if (N_ < 2 || N_ > 1024 || (N_ & 1)) { err = "size must be even and in [2, 1024]"; return MSM_ERR_INVALID; }
+    anyn_ = (N_ & (N_ - 1)) != 0 || N_ > 512;
+    lowdim_ = dims_ < 3 || anyn_;
+    pw_blocks_ = dims_ == 3 ? 1024 : 64;
     if (ns_ < 1) { err = "n_streams must be >= 1"; return MSM_ERR_INVALID; }
     if (cfg_.num_data_dumps == 0) { err = "num_data_dumps must be >= 1"; return MSM_ERR_INVALID; }
     n3_ = 1;
@@ -1932,11 +2041,12 @@ int Engine::init(std::string& err) {
     two_pass_ = (N_ == tp::N) && dims_ == 3;
     if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;   // 0: the generic three-pass engine
     // per-workgroup partials: the x-pass and z-pass tilings may differ
-    dispatch_n(N_, [&](auto nc) {
+    ntiles_ = pw_blocks_;
+    if (!anyn_) dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         tiles_x_ = (int)(n3_ / N / Geom<N, 0>::LPW);
         tiles_z_ = (int)(n3_ / N / Geom<N, 2>::LPW);
-        ntiles_ = std::max(std::max(tiles_x_, tiles_z_), PW_BLOCKS);
+        ntiles_ = std::max(std::max(tiles_x_, tiles_z_), pw_blocks_);
     });
 
     // ---- device memory
@@ -1983,6 +2093,46 @@ int Engine::init(std::string& err) {
         tw[p].y = (real)sinl(ang);
     }
     HIP_TRY(hipMemcpy(tw_, tw.data(), sizeof(cplx) * N_, hipMemcpyHostToDevice));
+    if (anyn_) {
+        // chirp-z tables in extended precision: c[n] = exp(-i pi n^2 / N) with n^2 reduced mod 2N exactly,
+        // the length-M spectrum of the wrapped conj(c) (bit-reversed, 1/M folded in), M-th roots of unity
+        typedef std::complex<long double> lc;
+        const long double pi = 3.141592653589793238462643383279502884L;
+        int M = 1;
+        while (M < 2 * N_ - 1) M <<= 1;
+        any_M_ = M;
+        any_lpw_ = 1;
+        for (int c : {8, 4, 2}) if (N_ % c == 0 && (size_t)c * M * sizeof(cplx) <= 65536) { any_lpw_ = c; break; }
+        std::vector<lc> ch(N_), b(M, lc(0, 0)), w(M / 2);
+        for (int n = 0; n < N_; ++n) {
+            const long long r = ((long long)n * n) % (2LL * N_);
+            const long double ang = -pi * (long double)r / (long double)N_;
+            ch[n] = lc(cosl(ang), sinl(ang));
+        }
+        b[0] = lc(1, 0);
+        for (int n = 1; n < N_; ++n) b[n] = b[M - n] = std::conj(ch[n]);
+        for (int k = 0; k < M / 2; ++k) {
+            const long double ang = -2.0L * pi * (long double)k / (long double)M;
+            w[k] = lc(cosl(ang), sinl(ang));
+        }
+        for (int half = M / 2, ts = 1; half >= 1; half >>= 1, ts <<= 1)      // decimation in frequency, output bit-reversed
+            for (int g = 0; g < M; g += 2 * half)
+                for (int j = 0; j < half; ++j) {
+                    const lc u = b[g + j], v = b[g + j + half];
+                    b[g + j] = u + v;
+                    b[g + j + half] = (u - v) * w[(size_t)j * ts];
+                }
+        std::vector<cplx> chr(N_), bh(M), twm(M / 2);
+        for (int n = 0; n < N_; ++n) { chr[n].x = (real)ch[n].real(); chr[n].y = (real)ch[n].imag(); }
+        for (int i = 0; i < M; ++i) { bh[i].x = (real)(b[i].real() / M); bh[i].y = (real)(b[i].imag() / M); }
+        for (int k = 0; k < M / 2; ++k) { twm[k].x = (real)w[k].real(); twm[k].y = (real)w[k].imag(); }
+        HIP_TRY(dmalloc((void**)&chirp_, sizeof(cplx) * N_));
+        HIP_TRY(dmalloc((void**)&bhat_, sizeof(cplx) * M));
+        HIP_TRY(dmalloc((void**)&twm_, sizeof(cplx) * (M / 2)));
+        HIP_TRY(hipMemcpy(chirp_, chr.data(), sizeof(cplx) * N_, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(bhat_, bh.data(), sizeof(cplx) * M, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(twm_, twm.data(), sizeof(cplx) * (M / 2), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(ksq_, ksq.data(), sizeof(real) * N_, hipMemcpyHostToDevice));
 
     // ---- per-stream state
@@ -2019,8 +2169,23 @@ void Engine::publish(bool fresh_max) {
     (void)hipMemcpyAsync(h_status_, st_.status, sizeof(msm_stream_status) * ns_, hipMemcpyDeviceToHost, stream_);
 }
 
+template <int SGN>
+void Engine::launch_any(int ax, const PsiArgs& p, int nblk_y, int kind) {
+    AnyArgs a{};
+    a.src = p.src; a.dst = p.dst; a.n3 = p.n3; a.active = p.active; a.s0 = p.s0; a.src_local = p.src_local;
+    a.dst_local = p.dst_local; a.N = N_; a.M = any_M_; a.chirp = chirp_; a.bhat = bhat_; a.twm = twm_; a.scale = p.scale;
+    a.stride = 1;
+    for (int i = 0; i < ax; ++i) a.stride *= (size_t)N_;
+    const size_t lines = n3_ / (size_t)N_;
+    a.lpw = (int)std::min<size_t>((size_t)any_lpw_, lines);        // a 1-D grid is one line
+    const dim3 grid((unsigned)(lines / a.lpw), (unsigned)nblk_y);
+    const size_t lds = (size_t)a.lpw * any_M_ * sizeof(cplx);
+    timed(kind, [&] { k_line_any<SGN><<<grid, dim3(256), lds, stream_>>>(a); });
+}
+
 template <int SGN, int LOAD, int STORE>
 void Engine::launch_psi(int ax, const PsiArgs& a0, int nblk_y, int kind) {
+    if (anyn_) { launch_any<SGN>(ax, a0, nblk_y, kind); return; }   // only plain passes exist on this path
     PsiArgs a = a0;
     const size_t lines = n3_ / (size_t)N_;
     a.nlines = (int)std::min<size_t>(lines, (size_t)1 << 30);
@@ -2158,20 +2323,20 @@ PwArgs Engine::pw_args(int s0, const int* act) const {
 void Engine::lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act) {
     PwArgs a = pw_args(s0, act);
     a.src = psi; a.src_local = local ? 1 : 0; a.scale = psi_scale;
-    const dim3 grid(PW_BLOCKS, (unsigned)nb), block(256);
+    const dim3 grid(pw_blocks_, (unsigned)nb), block(256);
     k_pw_rho<<<grid, block, 0, stream_>>>(a);
     fft3_plain(W_, true, W_, true, s0, nb, -1, act, false);
     k_pw_green<<<grid, block, 0, stream_>>>(a);
     fft3_plain(W_, true, W_, true, s0, nb, +1, act, false);
     if (store_phi) k_pw_phi<1><<<grid, block, 0, stream_>>>(a);
     else k_pw_phi<0><<<grid, block, 0, stream_>>>(a);
-    k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, PW_BLOCKS, s0, act);
+    k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, pw_blocks_, s0, act);
     if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
 // dims < 3: the rest of update (:504-635) with whole transforms and one kernel per pointwise operator
 void Engine::lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau) {
-    const dim3 grid(PW_BLOCKS, (unsigned)nb), block(256);
+    const dim3 grid(pw_blocks_, (unsigned)nb), block(256);
     PwArgs a = pw_args(s0, st_.active);
     // psi = F^-1[ D psi_k ]
     a.src = P_; a.src_local = 0; a.dst = X_; a.dst_local = 1;
@@ -2185,7 +2350,7 @@ void Engine::lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, 
     fft3_plain(X_, true, X_, true, s0, nb, -1, st_.active);
     a.src = X_; a.src_local = 1; a.dst = P_; a.dst_local = 0; a.scale = (real)1;
     k_pw_drift<1><<<grid, block, 0, stream_>>>(a);
-    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, PW_BLOCKS, s0, st_.active);
+    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, pw_blocks_, s0, st_.active);
     k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
     // potential of psi(t + dt) for the next timestep (:497)
     fft3_plain(P_, false, X_, true, s0, nb, +1, st_.active);

@@ -69,6 +69,7 @@ if __name__ == "__main__":
         "tophat_n8_f64": (TOPHAT, 8, -1, np.float64),
         "tophat_n16_f64": (TOPHAT, 16, -1, np.float64),
         "tophat_n16_f32": (TOPHAT, 16, -1, np.float32),
+        "tophat_n12_f64": (TOPHAT, 12, -1, np.float64),       # an edge that is not a power of two
         "planewave_n16_mft_f64": (PLANE, 16, -1, np.float64),
         "planewave_n16_wigner1_f64": (PLANE, 16, 0, np.float64),
     }

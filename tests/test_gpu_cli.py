@@ -228,6 +228,21 @@ def test_one_and_two_dimensional_runs(tmp_path, dims, size, flags):
             assert rel(got, psi) < 1e-11, (sim.parameters.sim_name, k)
 
 
+@pytest.mark.parametrize("size,flags", [(12, ()), (20, ("--expanding",))])
+def test_non_power_of_two_edge(tmp_path, size, flags):
+    # any even edge (utils/fft.rs:105): chirp-z line transforms and the unfused step behind the same process surface
+    cfg = dict(TOPHAT, sim_name="npo2", size=size, final_sim_time=0.3, num_data_dumps=3, sampling=dict(seeds="7", scheme="Husimi"))
+    if flags:
+        cfg["cosmology"] = dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01)
+    run_cli(tmp_path, cfg, *flags)
+    sims = oracle_runs(cfg, expanding=bool(flags))
+    assert [s.parameters.sim_name for s in sims] == ["npo2-stream00007", "npo2"]
+    for sim in sims:
+        assert len(sim.dumps) == 4
+        for k, psi in sim.dumps:
+            assert rel(load_dump(tmp_path, sim.parameters.sim_name, k), psi) < 1e-11, (sim.parameters.sim_name, k)
+
+
 def test_resume_from_last_dump(tmp_path):
     # --resume: a run cut after dump 2 continues from that dump and reproduces the uninterrupted run's later dumps
     # (the reference cannot restart: simulation_object.rs:627,915)

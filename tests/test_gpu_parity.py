@@ -168,7 +168,7 @@ def test_static_steps_128_f64():
 
 
 @pytest.mark.parametrize("name", ["tophat_n8_f64", "tophat_n16_f64", "planewave_n16_mft_f64",
-                                  "planewave_n16_wigner1_f64", "tophat_n16_f32", "tophat_n32_f64"])
+                                  "planewave_n16_wigner1_f64", "tophat_n16_f32", "tophat_n32_f64", "tophat_n12_f64"])
 def test_golden_vectors(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     base = TOPHAT if name.startswith("tophat") else PLANE
@@ -282,7 +282,9 @@ def test_sampling_matches_oracle_spec(scheme, golden_dir):
 
 def test_error_conventions():
     with pytest.raises(MsmError):
-        Evolver(size=24, n_streams=1, **TOPHAT)          # not a power of two
+        Evolver(size=25, n_streams=1, **TOPHAT)          # odd edge: get_kgrid asserts size % 2 == 0 (utils/fft.rs:105)
+    with pytest.raises(MsmError):
+        Evolver(size=2048, n_streams=1, dims=1, **TOPHAT)  # beyond the largest line transform
     with pytest.raises(MsmError):
         Evolver(size=16, n_streams=1, dims=4, **TOPHAT)  # dims is 1, 2 or 3
     with Evolver(size=8, n_streams=2, **TOPHAT) as ev:
