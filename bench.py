@@ -230,7 +230,7 @@ def main():
                        "density_allreduce": use_dist, "event_ms_per_step": ev_ms / args.steps},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # a reported baseline of the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(out), flush=True)
 
