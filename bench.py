@@ -44,25 +44,27 @@ KINDS = {
     "w_fwd_y": (1, 16.0), "poisson_z": (2, 16.0), "w_inv_y": (1, 16.0), "phi_inv_x": (1, 8.0),
     "rho_fwd_x": (1, 24.0), "plain": (1, 32.0),
 }
-# The 256^3 fp64 engine does a 3-D transform in two passes (x + outer half of y | inner half of y + z), so a
-# launch carries 1.5 axis passes per transform leg it performs; the kinds keep their names:
-#   psi_inv_z      pass B of psi = F^-1[D psi_k]                    psi_k in, T out
-#   psi_invx_rho   pass A of that inverse + rho + pass A of F[rho]  T in, pair-packed T out
-#   poisson_z      pass B of the Poisson solve, there and back      in place
-#   psi_fwd_x      pass A^-1 of phi, kick, pass A of F[psi]         W in, T in, T out
-#   psi_fwdz_invz  pass B of F[psi], drift, store psi_k, pass B^-1  T in, psi_k out, T out
-#   phi_inv_x      pass A^-1 of phi for max|phi|                    W in
+# The 256^3 engine does a 3-D transform in two passes (A: x + outer half of y | B: inner half of y + z), so a
+# launch carries 1.5 axis passes per transform leg it performs.  Between steps a stream's state is the pass-A image of
+# psi, so each kinetic half-step is one round trip through pass B and psi_k is never stored; the kinds keep their names:
+#   psi_inv_z      first half-drift: state -> B -> x D -> B^-1 (the B half of F^-1[D psi_k])   T in, T out
+#   psi_invx_rho   pass A^-1 of that inverse + rho + pass A of F[rho]                          T in, pair-packed T out
+#   poisson_z      pass B of the Poisson solve, there and back                                 in place
+#   psi_fwd_x      pass A^-1 of phi, kick, pass A of F[psi]                                    W in, T in, T out
+#   psi_fwdz_invz  pass B of F[psi], second half-drift, aliased mass, pass B^-1 -> new state   T in, T out
+#   phi_inv_x      pass A^-1 of phi for max|phi|                                               W in
+# Bytes moved per update: 32 + 24 + 16 + 40 + 32 + 24 + 16 + 8 = 192.
 KINDS_TWO_PASS = {
     "psi_inv_z": (1.5, 32.0), "psi_invx_rho": (3, 24.0), "poisson_z": (3, 16.0), "psi_fwd_x": (3, 40.0),
-    "psi_fwdz_invz": (3, 48.0), "phi_inv_x": (1.5, 8.0), "rho_fwd_x": (1.5, 24.0), "plain": (1.5, 32.0),
+    "psi_fwdz_invz": (3, 32.0), "phi_inv_x": (1.5, 8.0), "rho_fwd_x": (1.5, 24.0), "plain": (1.5, 32.0),
 }
 
 
 # pass kind -> kernel name in the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
 # command at 32 streams per launch, corrected as profiles/summarize_pmc.py documents)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic_32streams.json")
-PMC_KERNEL = {"psi_inv_z": "k_psi_b<1, 1>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
-              "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_b<2, 1>", "phi_inv_x": "k_phi_max3"}
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic_32streams.json")
+PMC_KERNEL = {"psi_inv_z": "k_psi_rt<0>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
+              "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_rt<1>", "phi_inv_x": "k_phi_max3"}
 
 
 def measured_traffic(kind, two_pass, cells_per_launch, n3):

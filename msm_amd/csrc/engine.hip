@@ -1019,15 +1019,15 @@ __global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4
     b_inverse(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
 }
 
-// Pass B of the psi transforms.  psi_k is kept as P[kx][ky][kz] (kz contiguous), which is what the
-// line role of this pass reads and writes in 256-byte rows.
-//   PB_FWD: T -> P                      (psi_k = F psi, unitary scale on store)
-//   PB_INV: P -> T, optional drift      (first pass of psi = F^-1[D psi_k], simulation_object.rs:504-528)
-//   PB_MID: T -> D F[.] -> P, aliased-mass partial, and straight back to T
-//           (simulation_object.rs:552-581 and check_alias :1249-1280)
+// Pass B of the psi transforms.  Between steps a stream's state is S = pass A of psi (psi after the forward x
+// lines and the outer y stage, in the T layout): psi_k = B[S] / N^{3/2} and psi = A^-1[S] / N^{3/2}, so psi_k
+// itself never has to be stored.  Both kinetic half-steps are then the same round trip through Fourier space,
+//   T -> pass B -> x D / N^{3/2} [-> aliased-mass partial] -> pass B^-1 -> T'
+// (first half: S -> scratch, simulation_object.rs:504-528; second half: kicked psi -> S, :552-581 with
+// check_alias :1249-1280), 16 B in and 16 B out per cell each.
 struct PsiBArgs {
-    cplx* T;             // [batch][n3], local stream index
-    cplx* P;             // [n_streams][n3], global stream index
+    const cplx* src;     // [.][n3] in the T layout, indexed by blockIdx.y
+    cplx* dst;           // [.][n3], indexed by blockIdx.y (T layout; k_psi_b_fwd: psi_k as [kx][ky][kz])
     size_t n3;
     const int* active;   // may be null
     int s0;
@@ -1038,76 +1038,82 @@ struct PsiBArgs {
     double* partial;     // [n_streams][ntiles]
     int ntiles;
 };
-enum { PB_FWD = 0, PB_INV = 1, PB_MID = 2 };
 
-template <int MODE, int DRIFT>
-__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_b(PsiBArgs a) {
+template <int ALIAS>
+__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_rt(PsiBArgs a) {
     constexpr int N = tp::N;
     __shared__ real plane[tp::B_PLANE];
     __shared__ cplx tw[N];
-    __shared__ double red[MODE == PB_MID ? tp::B_THREADS / 64 : 1];
-    constexpr bool USE_DRIFT = MODE == PB_MID || DRIFT;
-    __shared__ cplx dl[USE_DRIFT ? N : 1];      // this stream's 1-D drift factors
-    __shared__ real kq[MODE == PB_MID ? N : 1];  // k_i^2 table
+    __shared__ double red[ALIAS ? tp::B_THREADS / 64 : 1];
+    __shared__ cplx dl[N];                   // this stream's 1-D drift factors
+    __shared__ real kq[ALIAS ? N : 1];       // k_i^2 table
     const int tid = threadIdx.x;
     const int ls = blockIdx.y, sg = a.s0 + ls;
     if (a.active != nullptr && !a.active[sg]) return;
     // tables go to LDS up front: read from global memory in the middle of the kernel they would either expose an L2
     // round trip behind the transform or be hoisted into sixteen live register pairs
     if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];
-    else if (USE_DRIFT && tid < 2 * N) dl[tid - N] = a.drift[(size_t)sg * N + (tid - N)];
-    else if (MODE == PB_MID && tid < 3 * N) kq[tid - 2 * N] = a.ksq[tid - 2 * N];
-    lds_barrier();   // the z lines exchange inside their wavefront: PB_INV would otherwise reach the table with no barrier in between
+    else if (tid < 2 * N) dl[tid - N] = a.drift[(size_t)sg * N + (tid - N)];
+    else if (ALIAS && tid < 3 * N) kq[tid - 2 * N] = a.ksq[tid - 2 * N];
+    lds_barrier();   // the z lines exchange inside their wavefront: no other barrier lies before the first table read
     const RunB rb;
     const RolesB r(plane);
     const size_t trun = (size_t)ls * a.n3 + rb.off;
     const unsigned toff = rb.toff;
-    const int kx = rb.kx(r), ky = rb.ky(r);
-    cplx* __restrict__ prow = a.P + (size_t)sg * a.n3 + ((size_t)kx * N + ky) * N + r.j0;
-    const cplx* d = dl;
 
     cplx v[16];
-    if constexpr (MODE != PB_INV) {
-        b_forward(v, a.T, trun, toff, rb.tpi, r, tw, a.tw);
-        if constexpr (MODE == PB_MID || DRIFT) {
-            const cplx dxy = cmul(d[kx], d[ky]);
+    b_forward(v, a.src, trun, toff, rb.tpi, r, tw, a.tw);
+    const int kx = rb.kx(r), ky = rb.ky(r);
+    {
+        const cplx dxy = cscale(cmul(dl[kx], dl[ky]), a.scale);
+        // four factors at a time: all sixteen table reads hoisted to the front would not fit the register budget
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(dxy, d[r.j0 + 16 * q]));
-        }
+        for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            v[q] = cscale(v[q], a.scale);
-            prow[16 * q] = v[q];
-        }
-        if constexpr (MODE == PB_MID) {
-            const real kxy = kq[kx] + kq[ky];
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const real k2 = (kxy + kq[r.j0 + 16 * q]) * a.fourpi2;
-                if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-            if ((tid & 63) == 0) red[tid >> 6] = acc;
-            lds_barrier();   // also frees the plane for the way back
-            if (tid == 0) {
-                double tot = red[0];
-#pragma unroll
-                for (int w = 1; w < tp::B_THREADS / 64; ++w) tot += red[w];
-                a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = prow[16 * q];
-        if constexpr (DRIFT) {
-            const cplx dxy = cmul(d[kx], d[ky]);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(dxy, d[r.j0 + 16 * q]));
+            for (int i = 0; i < 4; ++i) v[4 * c + i] = cmul(v[4 * c + i], cmul(dxy, dl[r.j0 + 16 * (4 * c + i)]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if constexpr (MODE != PB_FWD) b_inverse(v, a.T, trun, toff, rb.tpi, r, tw, a.tw);
+    if constexpr (ALIAS) {
+        const real kxy = kq[kx] + kq[ky];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const real k2 = (kxy + kq[r.j0 + 16 * q]) * a.fourpi2;
+            if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        lds_barrier();
+        if (tid == 0) {
+            double tot = red[0];
+#pragma unroll
+            for (int w = 1; w < tp::B_THREADS / 64; ++w) tot += red[w];
+            a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
+        }
+    }
+    b_inverse(v, a.dst, trun, toff, rb.tpi, r, tw, a.tw);
+}
+
+// psi_k = B[S] / N^{3/2} written as [kx][ky][kz] (kz contiguous, 256-byte rows): downloads of psi_k and the
+// synthesizer's psi_k products; k_transpose_xz turns it into the reference's element order.
+__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_b_fwd(PsiBArgs a) {
+    constexpr int N = tp::N;
+    __shared__ real plane[tp::B_PLANE];
+    __shared__ cplx tw[N];
+    const int tid = threadIdx.x;
+    const int ls = blockIdx.y, sg = a.s0 + ls;
+    if (a.active != nullptr && !a.active[sg]) return;
+    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];   // first read is behind the role-change barriers
+    const RunB rb;
+    const RolesB r(plane);
+    const int kx = rb.kx(r), ky = rb.ky(r);
+    cplx* __restrict__ prow = a.dst + (size_t)ls * a.n3 + ((size_t)kx * N + ky) * N + r.j0;
+    cplx v[16];
+    b_forward(v, a.src, (size_t)ls * a.n3 + rb.off, rb.toff, rb.tpi, r, tw, a.tw);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) prow[16 * q] = cscale(v[q], a.scale);
 }
 
 // Pass A of a plain psi transform: natural layout <-> T.
@@ -1847,8 +1853,10 @@ class Engine final : public IEngine {
     void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
     // act = all_active_ solves for finished streams too (standalone msm_potential)
     void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act);
-    // two-pass psi transforms (two_pass_): pass B between P and the T-layout scratch X_, pass A between T and a natural grid
-    void psi_b(int mode, bool drift, int s0, int n, const int* act, int kind);
+    // two-pass psi transforms (two_pass_): the kinetic round trip through pass B, psi_k for downloads, and pass A
+    // between T and a natural grid.  src/dst are indexed by the launch's local stream number.
+    void psi_rt(const cplx* src, cplx* dst, bool alias, int s0, int n, const int* act, int kind);
+    void psi_b_fwd(const cplx* src, cplx* dst, int s0, int n);
     void psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act);
     void first_step_init(int s0, int nb);
     void step_front(int s0, int nb);
@@ -1890,7 +1898,7 @@ class Engine final : public IEngine {
     int any_M_ = 0, any_lpw_ = 1;
     cplx *chirp_ = nullptr, *bhat_ = nullptr, *twm_ = nullptr;
     template <int SGN> void launch_any(int ax, const PsiArgs& a, int nblk_y, int kind);
-    bool two_pass_ = false;  // every 3-D transform in two passes (N = 256, double); psi_k is then kept as P[kx][ky][kz]
+    bool two_pass_ = false;  // every 3-D transform in two passes (N = 256); P_ then holds S = pass A of psi between steps
     cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
     int phi_s0_ = -1, phi_nb_ = 0;
@@ -2282,19 +2290,21 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
     poisson_tail(s0, nb, store_phi, track_max, true, act);
 }
 
-void Engine::psi_b(int mode, bool drift, int s0, int n, const int* act, int kind) {
+void Engine::psi_rt(const cplx* src, cplx* dst, bool alias, int s0, int n, const int* act, int kind) {
     PsiBArgs b{};
-    b.T = X_; b.P = P_; b.n3 = n3_; b.active = act; b.s0 = s0; b.tw = tw_; b.drift = st_.drift; b.ksq = ksq_;
+    b.src = src; b.dst = dst; b.n3 = n3_; b.active = act; b.s0 = s0; b.tw = tw_; b.drift = st_.drift; b.ksq = ksq_;
     b.scale = c_.unit_scale; b.alias_cut = c_.alias_cut; b.fourpi2 = c_.fourpi2; b.partial = partial_; b.ntiles = ntiles_;
-    {
-        const dim3 grid(tp::B_BLOCKS, (unsigned)n), block(tp::B_THREADS);
-        timed(kind, [&] {
-            if (mode == PB_FWD) k_psi_b<PB_FWD, 0><<<grid, block, 0, stream_>>>(b);
-            else if (mode == PB_MID) k_psi_b<PB_MID, 1><<<grid, block, 0, stream_>>>(b);
-            else if (drift) k_psi_b<PB_INV, 1><<<grid, block, 0, stream_>>>(b);
-            else k_psi_b<PB_INV, 0><<<grid, block, 0, stream_>>>(b);
-        });
-    }
+    const dim3 grid(tp::B_BLOCKS, (unsigned)n), block(tp::B_THREADS);
+    timed(kind, [&] {
+        if (alias) k_psi_rt<1><<<grid, block, 0, stream_>>>(b);
+        else k_psi_rt<0><<<grid, block, 0, stream_>>>(b);
+    });
+}
+
+void Engine::psi_b_fwd(const cplx* src, cplx* dst, int s0, int n) {
+    PsiBArgs b{};
+    b.src = src; b.dst = dst; b.n3 = n3_; b.active = nullptr; b.s0 = s0; b.tw = tw_; b.scale = c_.unit_scale;
+    timed(PK_PLAIN, [&] { k_psi_b_fwd<<<dim3(tp::B_BLOCKS, (unsigned)n), dim3(tp::B_THREADS), 0, stream_>>>(b); });
 }
 
 void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act) {
@@ -2367,8 +2377,9 @@ void Engine::first_step_init(int s0, int nb) {
     }
     poisson_from_psi(P_, false, s0, nb, false, true, st_.active);
     if (two_pass_) {
-        psi_a(-1, P_, false, X_, true, s0, nb, st_.active);
-        psi_b(PB_FWD, false, s0, nb, st_.active, PK_PLAIN);
+        // the state becomes S = pass A of psi, for every stream of the batch (finished ones too: downloads read S)
+        psi_a(-1, P_, false, X_, true, s0, nb, nullptr);
+        (void)hipMemcpyAsync(P_ + (size_t)s0 * n3_, X_, sizeof(cplx) * n3_ * (size_t)nb, hipMemcpyDeviceToDevice, stream_);
     } else {
         fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
     }
@@ -2391,16 +2402,22 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     if (two_pass_) {
         {
             const dim3 gridA(tp::A_TILES), gridAp(tp::A_TILES, (unsigned)((nb + 1) / 2)), blockA(tp::A_THREADS);
-            // psi = F^-1[ D psi_k ]: pass B with the whole drift factor, pass A fused with rho and the Poisson pass A
-            psi_b(PB_INV, true, s0, nb, st_.active, PK_INV_Z);
+            // The whole step runs in place on the batch's states S (contiguous in P_): every kernel reads a tile or a
+            // run completely before it stores it, and tiles and runs are disjoint between workgroups.
+            cplx* S = P_ + (size_t)s0 * n3_;
+            p.X = S; p.Xout = S;
+            // psi = F^-1[ D psi_k ]: round trip of S through pass B with the whole drift factor in between, then
+            // pass A^-1 fused with rho and the Poisson pass A
+            psi_rt(S, S, false, s0, nb, st_.active, PK_INV_Z);
             timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p); });
             poisson_tail(s0, nb, false, false, false);
-            // kick between the two A passes; pass B applies the second drift, stores psi_k and turns round
+            // kick between the two A passes; the second round trip applies the second drift, sums the aliased mass
+            // and leaves the new state
             timed(PK_FWD_X, [&] { k_kick3<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); });
-            psi_b(PB_MID, true, s0, nb, st_.active, PK_FWDZ_INVZ);
+            psi_rt(S, S, true, s0, nb, st_.active, PK_FWDZ_INVZ);
             k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::B_BLOCKS, s0, st_.active);
             k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
-            p.dens = step_dens_;
+            p.dens = step_dens_;               // potential of psi(t + dt) straight from the state
             timed(PK_INVX_RHO, [&] {
                 if (step_dens_) k_invx_rho3<1><<<gridA, blockA, 0, stream_>>>(p);
                 else k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p);
@@ -2550,9 +2567,9 @@ int Engine::potential(int first, int count, std::string& err) {
             lowdim_poisson(P_, false, (real)1, first, count, true, all_active_);
         }
     } else if (fourier_ && two_pass_) {
-        psi_b(PB_INV, false, first, count, nullptr, PK_PLAIN);
         {
-            const PoisArgs p = pois_args(first, count, all_active_);
+            PoisArgs p = pois_args(first, count, all_active_);
+            p.X = P_ + (size_t)first * n3_;
             timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p); });
         }
         poisson_tail(first, count, true, true, true, all_active_);
@@ -2625,8 +2642,7 @@ int Engine::planes_of(int s, bool kspace, real* stage, std::string& err) {
     if (!kspace && fourier_) {
         // psi = F^-1 psi_k (simulation_object.rs:581), materialised on demand in the batch scratch
         if (two_pass_) {
-            psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
-            psi_a(+1, X_, true, W_, true, s, 1, nullptr);
+            psi_a(+1, src, true, W_, true, s, 1, nullptr);
             src = W_;
         } else {
             fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
@@ -2634,8 +2650,9 @@ int Engine::planes_of(int s, bool kspace, real* stage, std::string& err) {
         }
     } else if (kspace && two_pass_) {
         const unsigned nb32 = (unsigned)(N_ / 32);
-        k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(src, X_, N_);
-        src = X_;
+        psi_b_fwd(src, X_, s, 1);
+        k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(X_, W_, N_);
+        src = W_;
     }
     k_split<<<2048, 256, 0, stream_>>>(src, stage, stage + n3_, n3_);
     HIP_TRY(hipGetLastError());
@@ -2724,8 +2741,7 @@ int Engine::density_sum(void* dev_out, std::string& err) {
         k_density_sum<<<2048, 256, 0, stream_>>>(P_, n3_, ns_, (double*)dev_out, 0);
     } else if (two_pass_) {
         for (int s = 0; s < ns_; ++s) {
-            psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
-            psi_a(+1, X_, true, W_, true, s, 1, nullptr);
+            psi_a(+1, P_ + (size_t)s * n3_, true, W_, true, s, 1, nullptr);
             k_density_sum<<<2048, 256, 0, stream_>>>(W_, n3_, 1, (double*)dev_out, s > 0 ? 1 : 0);
         }
     } else {
@@ -2777,12 +2793,13 @@ void Engine::materialise(int s, const cplx** psi, const cplx** psik) {
         *psi = P_ + (size_t)s * n3_;
         *psik = X_;
     } else if (two_pass_) {
-        psi_b(PB_INV, false, s, 1, nullptr, PK_PLAIN);
-        psi_a(+1, X_, true, W_, true, s, 1, nullptr);
+        const cplx* S = P_ + (size_t)s * n3_;
+        psi_a(+1, S, true, W_, true, s, 1, nullptr);
+        psi_b_fwd(S, X_, s, 1);
         const unsigned nb32 = (unsigned)(N_ / 32);
-        k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(P_ + (size_t)s * n3_, X_, N_);
+        k_transpose_xz<<<dim3(nb32, nb32, (unsigned)N_), 256, 0, stream_>>>(X_, stage_, N_);
         *psi = W_;
-        *psik = X_;
+        *psik = stage_;
     } else {
         fft3_plain(P_, false, X_, true, s, 1, +1, nullptr);
         *psi = X_;

@@ -406,7 +406,7 @@ def _run_mode_256(mode, cosmology=None, precision="f64"):
                          ids=["static", "expanding"])
 @pytest.mark.parametrize("precision,tol,stol", [("f64", 1e-11, 1e-11), ("f32", 2e-4, 2e-5)])
 def test_two_pass_engine_matches_three_pass_256(cosmology, precision, tol, stol):
-    """The 256^3 two-pass engine (blocked work-array layouts, psi_k kept transposed) against the
+    """The 256^3 two-pass engine (blocked work-array layouts, state kept as the pass-A image of psi) against the
     plain three-passes-per-transform engine that the small-N oracle tests pin: same steps, same
     activity flags, fields equal to rounding -- with an unpaired stream and a stream that drops out."""
     r3, psi3, psik3, phi3 = _run_mode_256(0, cosmology, precision)
@@ -416,14 +416,15 @@ def test_two_pass_engine_matches_three_pass_256(cosmology, precision, tol, stol)
         for x, y in zip(a, b):
             assert x[4:] == y[4:]
             assert abs(x[0] / y[0] - 1) < stol and abs(x[1] / y[1] - 1) < stol
-            # fp32: phi of a nearly uniform density is a difference of nearly equal numbers
-            assert abs(x[2] / y[2] - 1) < (stol if precision == "f64" else 5e-3)
+            # phi of a nearly uniform density (1 + 1e-3 noise) is a difference of nearly equal numbers: the relative
+            # rounding error of max|phi| is ~1e3 times that of psi
+            assert abs(x[2] / y[2] - 1) < (5 * stol if precision == "f64" else 5e-3)
             assert abs(x[3] - y[3]) <= (1e-9 if precision == "f64" else 1e-3) * max(abs(x[3]), 1e-30) + (1e-22 if precision == "f64" else 1e-12)
     for s in range(5):
         assert rel_err(psi2[s], psi3[s]) < tol
         assert rel_err(psik2[s], psik3[s]) < tol
     for s in range(4):
-        assert rel_err(phi2[s], phi3[s]) < (tol if precision == "f64" else 1e-2)
+        assert rel_err(phi2[s], phi3[s]) < (5 * tol if precision == "f64" else 1e-2)     # ill-conditioned, as max|phi| above
 
 
 def test_config5_shape_512_f32_expanding():
