@@ -1859,6 +1859,12 @@ class Engine final : public IEngine {
     void psi_b_fwd(const cplx* src, cplx* dst, int s0, int n);
     void psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act);
     void first_step_init(int s0, int nb);
+    // first step: every batch changes representation, also one whose streams have all finished already (a restart)
+    void enter_fourier() {
+        if (fourier_) return;
+        for (int s0 = 0; s0 < ns_; s0 += batch_) first_step_init(s0, std::min(batch_, ns_ - s0));
+        fourier_ = true;
+    }
     void step_front(int s0, int nb);
     void step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
     void publish(bool fresh_max = false);
@@ -2372,7 +2378,7 @@ void Engine::lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, 
 void Engine::first_step_init(int s0, int nb) {
     if (lowdim_) {
         lowdim_poisson(P_, false, (real)1, s0, nb, false, st_.active);
-        fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
+        fft3_plain(P_, false, P_, false, s0, nb, -1, nullptr);   // finished streams too: downloads read the new form
         return;
     }
     poisson_from_psi(P_, false, s0, nb, false, true, st_.active);
@@ -2381,7 +2387,7 @@ void Engine::first_step_init(int s0, int nb) {
         psi_a(-1, P_, false, X_, true, s0, nb, nullptr);
         (void)hipMemcpyAsync(P_ + (size_t)s0 * n3_, X_, sizeof(cplx) * n3_ * (size_t)nb, hipMemcpyDeviceToDevice, stream_);
     } else {
-        fft3_plain(P_, false, P_, false, s0, nb, -1, st_.active);
+        fft3_plain(P_, false, P_, false, s0, nb, -1, nullptr);
     }
 }
 
@@ -2484,12 +2490,11 @@ int Engine::step(std::string& err) {
     if (in_step_) { err = "msm_step inside an open msm_step_begin"; return MSM_ERR_STATE; }
     phi_s0_ = -1;   // the batch potential buffer is not maintained by steps
     if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
+    enter_fourier();
     for_batches([&](int s0, int nb) {
-        if (!fourier_) first_step_init(s0, nb);
         step_front(s0, nb);
         step_back(s0, nb, nullptr, nullptr, nullptr);
     });
-    fourier_ = true;
     publish();
     HIP_TRY(hipGetLastError());
     return MSM_OK;
@@ -2504,11 +2509,8 @@ int Engine::step_begin(const double* a_now, const double* tau_next, std::string&
     HIP_TRY(hipMemcpyAsync(st_.a_now, a.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(st_.tau_next, t.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));  // the host vectors die here
-    for_batches([&](int s0, int nb) {
-        if (!fourier_) first_step_init(s0, nb);
-        step_front(s0, nb);
-    });
-    fourier_ = true;
+    enter_fourier();
+    for_batches([&](int s0, int nb) { step_front(s0, nb); });
     publish();
     in_step_ = true;
     HIP_TRY(hipGetLastError());

@@ -524,6 +524,29 @@ def test_async_download_and_restart_clock():
             ev2.set_clock(0, 0.0, 0.0, 0)      # only before the first step
 
 
+@pytest.mark.parametrize("N,batch", [(16, 2), (256, 2)])
+def test_streams_finished_before_the_first_step_keep_their_field(N, batch):
+    """A restart can hand over streams that are already at the final time (msm_set_clock): they never step, alone in
+    a batch or next to a live stream, and their psi and psi_k still download correctly after the others have moved on."""
+    rng = np.random.default_rng(N)
+    psis = [o.normalize(1.0 + 1e-3 * (rng.standard_normal((N,) * 3) + 1j * rng.standard_normal((N,) * 3)), 30.0 / N, 3)
+            for _ in range(4)]
+    with Evolver(size=N, n_streams=4, batch_streams=batch, **TOPHAT) as ev:
+        for s in range(4):
+            ev.set_psi(s, psis[s])
+        ev.set_clock(1, TOPHAT["final_sim_time"], 0.0, TOPHAT["num_data_dumps"])      # next to live stream 0
+        ev.set_clock(2, TOPHAT["final_sim_time"], 0.0, TOPHAT["num_data_dumps"])      # batch {2, 3}: both finished
+        ev.set_clock(3, TOPHAT["final_sim_time"], 0.0, TOPHAT["num_data_dumps"])
+        ev.update()
+        ev.update()
+        st = ev.status()
+        assert [r.active for r in st] == [1, 0, 0, 0] and [r.n_steps for r in st] == [2, 0, 0, 0]
+        for s in (1, 2, 3):
+            assert rel_err(ev.get_psi(s), psis[s]) < 1e-13
+            assert rel_err(ev.get_psik(s), o.forward(psis[s])) < 1e-13
+        assert rel_err(ev.get_psi(0), psis[0]) > 1e-9
+
+
 _DENSITY_SCRIPT = r"""
 import sys
 import numpy as np
