@@ -1907,6 +1907,12 @@ class Engine final : public IEngine {
     bool two_pass_ = false;  // every 3-D transform in two passes (N = 256); P_ then holds S = pass A of psi between steps
     cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
+    // captured static step of small grids
+    static constexpr size_t GRAPH_MAX_CELLS = (size_t)1 << 23;
+    bool graph_ok_ = true;
+    hipGraphExec_t graph_exec_ = nullptr;
+    std::vector<char> graph_key_;
+    double* graph_dens_ = nullptr;
     int phi_s0_ = -1, phi_nb_ = 0;
     std::vector<void*> allocs_;
     int planes_of(int s, bool kspace, real* stage, std::string& err);
@@ -1958,6 +1964,7 @@ void Engine::release() {
     }
     for (auto& sl : synth_) if (sl.sums) (void)hipFree(sl.sums);
     synth_.clear();
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
     if (h_status_) (void)hipHostFree(h_status_);
@@ -2052,6 +2059,8 @@ int Engine::init(std::string& err) {
     c_.inv_n3 = (real)(1.0 / (double)n3_);
     c_.unit_scale = (real)(1.0 / std::pow((double)N_, dims_ / 2.0));
 
+    if (const char* e = getenv("MSM_GRAPH")) graph_ok_ = atoi(e) != 0;     // 0: plain launches for small grids too
+    if (!own_stream_ && stream_ == nullptr) graph_ok_ = false;               // the legacy default stream cannot be captured
     two_pass_ = (N_ == tp::N) && dims_ == 3;
     if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;   // 0: the generic three-pass engine
     // per-workgroup partials: the x-pass and z-pass tilings may differ
@@ -2489,13 +2498,53 @@ int Engine::step(std::string& err) {
     if (cfg_.expanding) { err = "expanding contexts step with msm_step_begin / msm_step_end"; return MSM_ERR_STATE; }
     if (in_step_) { err = "msm_step inside an open msm_step_begin"; return MSM_ERR_STATE; }
     phi_s0_ = -1;   // the batch potential buffer is not maintained by steps
-    if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
     enter_fourier();
-    for_batches([&](int s0, int nb) {
-        step_front(s0, nb);
-        step_back(s0, nb, nullptr, nullptr, nullptr);
-    });
-    publish();
+    auto body = [&]() -> hipError_t {
+        if (step_dens_) { hipError_t e = hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_); if (e != hipSuccess) return e; }
+        for_batches([&](int s0, int nb) {
+            step_front(s0, nb);
+            step_back(s0, nb, nullptr, nullptr, nullptr);
+        });
+        publish();
+        return hipSuccess;
+    };
+    // Small grids are bound by the host's launch rate (a step is ~25 launches of a few microseconds each): their step
+    // is captured once into a HIP graph and replayed.  Every argument of every launch is constant from step to step
+    // (dt, flags and counters live in device memory); only the set of batches that still have a live stream and the
+    // density target can change, and either re-captures.
+    if (graph_ok_ && !prof_on_ && n3_ * (size_t)ns_ <= GRAPH_MAX_CELLS) {
+        std::vector<char> key;
+        for (int s0 = 0; s0 < ns_; s0 += batch_) {
+            char any = 0;
+            for (int i = s0; i < std::min(ns_, s0 + batch_); ++i) any |= (char)(host_active_[i] != 0);
+            key.push_back(any);
+        }
+        if (!graph_exec_ || key != graph_key_ || graph_dens_ != step_dens_) {
+            if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                const hipError_t eb = body();
+                e = hipStreamEndCapture(stream_, &g);
+                if (e == hipSuccess) e = eb;
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {            // no graphs on this stream: plain launches from now on
+                (void)hipGetLastError();
+                graph_exec_ = nullptr;
+                graph_ok_ = false;
+            } else {
+                graph_key_ = key;
+                graph_dens_ = step_dens_;
+            }
+        }
+        if (graph_exec_) {
+            HIP_TRY(hipGraphLaunch(graph_exec_, stream_));
+            return MSM_OK;
+        }
+    }
+    HIP_TRY(body());
     HIP_TRY(hipGetLastError());
     return MSM_OK;
 }
