@@ -104,6 +104,30 @@ def test_user_specified_wigner_and_potential(tmp_path, golden_dir):
         assert rel(phi.real, sim.calculate_potential()) < 1e-11 and not phi.imag.any()
 
 
+def test_repro_example_1d_aliases_as_the_oracle_does(tmp_path, golden_dir):
+    # examples/repro.toml as a static box: the reference's 1-D fixture planeWave1d.npz (256 points), Wigner streams.
+    # With these constants the first stream collapses onto the grid scale and trips check_alias after a few hundred
+    # steps (simulation_object.rs:607-617): the run must die at the same step with the same aliased mass.
+    cfg = dict(axis_length=60.0, final_sim_time=1000.0, cfl=0.1, num_data_dumps=128, total_mass=3e16, hbar_=0.01,
+               sim_name="planeWave1d", ntot=1e12, k2_cutoff=0.95, alias_threshold=0.001, dims=1, size=256,
+               ics=dict(type="UserSpecified", path=os.path.join(golden_dir, "planeWave1d.npz")),
+               cosmology=dict(omega_matter_now=1.0, omega_radiation_now=0.0, h=1e-07, z0=99.0, max_dloga=0.01),
+               sampling=dict(num_streams=128, seeds="1 to 1", scheme="Wigner"))
+    r = run_cli(tmp_path, cfg, expect=101)
+    sim = o.SimulationObject(next(iter(o.simulation_iter(cfg))))
+    psi0 = sim.psi.copy()
+    with pytest.raises(RuntimeError) as exc:
+        for _ in range(5000):
+            sim.update()
+    want = float(str(exc.value).split("p_mass is ")[1].split()[0])
+    got = float(r.stderr.split("p_mass is ")[1].split()[0])
+    assert 200 < sim.parameters.n_steps < 1000 and abs(got / want - 1) < 1e-5, (got, want)
+    assert "(planeWave1d-stream00001)" in r.stderr
+    base = tmp_path / "sim-data" / "planeWave1d-stream00001" / "psi_00000"
+    re, im = np.load(open(str(base) + "_real", "rb")), np.load(open(str(base) + "_imag", "rb"))
+    assert re.shape == (256, 1, 1, 1) and rel((re + 1j * im).reshape(256), psi0) < 1e-13
+
+
 def test_expanding_box(tmp_path):
     # examples/spherical-tophat-cosmo.toml under the reference's feature "expanding" (test.sh:6)
     cfg = dict(TOPHAT, sim_name="spherical-tophat-cosmo", final_sim_time=0.6, num_data_dumps=3,

@@ -164,6 +164,18 @@ def test_scale_factor_einstein_de_sitter():
     assert abs(tau / (pref * (f(tgt) - f(0.0))) - 1) < 1e-6
 
 
+def test_planewave_1d_fixture(golden_dir):
+    # the reference's own 1-D initial conditions (planeWave1d.npz beside examples/repro.toml): 256 points, unit norm
+    path = os.path.join(golden_dir, "planeWave1d.npz")
+    psi = o.user_specified_ics(path, 1, 256)
+    assert psi.shape == (256,) and psi.dtype == np.complex128
+    assert abs(np.sum(np.abs(psi) ** 2) * 60.0 / 256 - 1.0) < 1e-12
+    with pytest.raises(ValueError):
+        o.user_specified_ics(path, 1, 128)
+    with pytest.raises(ValueError):
+        o.user_specified_ics(path, 2, 256)
+
+
 def test_goldens_regenerate(golden_dir):
     # the committed vectors are what the oracle produces today (guards oracle drift)
     g = np.load(os.path.join(golden_dir, "tophat_n8_f64.npz"))
