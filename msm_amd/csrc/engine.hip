@@ -253,6 +253,22 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
     }
 }
 
+// Waves per SIMD at which a generic pass kernel fills the CU as far as its LDS tile allows: the register allocator is
+// told to stay within 512 / that many VGPRs, so that the workgroups the LDS admits really are resident together
+// (in single precision the tiles are half as large and the kernels otherwise settle on one workgroup per CU).
+template <int N, int AX>
+constexpr int occ_waves() {
+    using G = Geom<N, AX>;
+    const int bytes = (int)(G::LDS_ELEMS * sizeof(cplx)) + 4096;      // tile + twiddles + reduction scratch
+    const int wpw = G::THREADS >= 64 ? G::THREADS / 64 : 1;          // waves per workgroup
+    int wgs = 163840 / bytes;
+    if (wgs > 32 / wpw) wgs = 32 / wpw;
+    if (wgs < 1) wgs = 1;
+    int w = wgs * wpw / 4;
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+#define MSM_OCC(N, AX) __attribute__((amdgpu_waves_per_eu(occ_waves<N, AX>())))
+
 // ---------------------------------------------------------------------------
 // generic axis pass: transforms of psi / psi_k and the plain passes on W
 // ---------------------------------------------------------------------------
@@ -277,7 +293,7 @@ struct PsiArgs {
 //       2 kick psi *= exp(i kick phi)                                 (simulation_object.rs:535-545)
 // STORE: 0 scale only, 1 drift table times scale                      (simulation_object.rs:562-574)
 template <int N, int SGN, int AX, int LOAD, int STORE>
-__global__ __launch_bounds__((Geom<N, AX>::THREADS)) void k_psi_pass(PsiArgs a) {
+__global__ __launch_bounds__((Geom<N, AX>::THREADS)) MSM_OCC(N, AX) void k_psi_pass(PsiArgs a) {
     using G = Geom<N, AX>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
@@ -362,7 +378,7 @@ struct FzArgs {
 };
 
 template <int N>
-__global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_fwdz_invz(FzArgs a) {
+__global__ __launch_bounds__((Geom<N, 2>::THREADS)) MSM_OCC(N, 2) void k_fwdz_invz(FzArgs a) {
     using G = Geom<N, 2>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
@@ -428,7 +444,7 @@ struct PoisArgs {
 // x pass, forward, from a stored psi: rho = M |psi|^2 of both streams of the pair
 // (calculate_density, simulation_object.rs:1031-1063).
 template <int N>
-__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_rho_pass(PoisArgs a) {
+__global__ __launch_bounds__((Geom<N, 0>::THREADS)) MSM_OCC(N, 0) void k_rho_pass(PoisArgs a) {
     using G = Geom<N, 0>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
@@ -565,41 +581,95 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a,
     load_twiddles<N, 0>(tw, a.tw);
     cplx* line = lds + t.ln * G::LINE_LDS;
 
-    real phi[2][E];
-    {
-        const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-        cplx vw[E];
+    if constexpr (sizeof(real) == 4) {
+        // Single precision has the registers to let the loads run ahead of their use (one 8-wave workgroup per CU would
+        // otherwise wait out every load): psi_a is fetched together with W, psi_b before psi_a is worked on.  A finished
+        // (or absent) stream of the pair is still transformed -- its scratch slot exists -- and only its store is skipped,
+        // so that the code is one straight line.
+        const int sbs = (2 * p + 1 < a.nb) ? sb : sa;               // tables of an absent partner: any valid row
+        cplx* __restrict__ xa = a.Xout + (size_t)(2 * p) * a.n3;
+        cplx* __restrict__ xb = a.Xout + (size_t)(2 * p + 1) * a.n3;
+        const cplx* __restrict__ da = a.drift + (size_t)sa * N;
+        const cplx* __restrict__ db = a.drift + (size_t)sbs * N;
+        const real kca = kick[sa], kcb = kick[sbs];
+        real phi[2][E];
+        cplx va[E], vb[E];
+        {
+            const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+            cplx vw[E];
 #pragma unroll
-        for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
-        LineFft<real, N, +1, true>::run(vw, t.j0, line, tw);
+            for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
 #pragma unroll
-        for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
-    }
+            for (int q = 0; q < E; ++q) va[q] = xa[t.base + t.j0 + TPL * q];
+            LineFft<real, N, +1, true>::run(vw, t.j0, line, tw);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool act = h == 0 ? act_a : act_b;
-        if (!act) continue;   // uniform over the workgroup
-        const int sg = h == 0 ? sa : sb;
-        cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
-        const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-        const real kc = kick[sg];
-        if constexpr (G::USES_LDS) exch_sync<true>();   // also keeps the psi loads below the previous transform
-        cplx v[E];
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-        LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            real sn, cs;
-            sincos_t(kc * phi[h][q], &sn, &cs);
-            v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
+            for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
         }
-        if constexpr (G::USES_LDS) exch_sync<true>();
-        LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
+        auto one = [&](cplx (&v)[E], const cplx* __restrict__ d, real kc, const real (&ph)[E]) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
+            for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+            if constexpr (G::USES_LDS) exch_sync<true>();
+            LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                real sn, cs;
+                sincos_t(kc * ph[q], &sn, &cs);
+                v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
+            }
+            if constexpr (G::USES_LDS) exch_sync<true>();
+            LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+        };
+#pragma unroll
+        for (int q = 0; q < E; ++q) vb[q] = xb[t.base + t.j0 + TPL * q];
+        one(va, da, kca, phi[0]);
+        if (act_a) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) xa[t.base + t.j0 + TPL * q] = va[q];
+        }
+        one(vb, db, kcb, phi[1]);
+        if (act_b) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) xb[t.base + t.j0 + TPL * q] = vb[q];
+        }
+    } else {
+        real phi[2][E];
+        {
+            const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
+            cplx vw[E];
+#pragma unroll
+            for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
+            LineFft<real, N, +1, true>::run(vw, t.j0, line, tw);
+#pragma unroll
+            for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool act = h == 0 ? act_a : act_b;
+            if (!act) continue;   // uniform over the workgroup
+            const int sg = h == 0 ? sa : sb;
+            cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
+            const cplx* __restrict__ d = a.drift + (size_t)sg * N;
+            const real kc = kick[sg];
+            if constexpr (G::USES_LDS) exch_sync<true>();   // also keeps the psi loads below the previous transform
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
+            LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                real sn, cs;
+                sincos_t(kc * phi[h][q], &sn, &cs);
+                v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
+            }
+            if constexpr (G::USES_LDS) exch_sync<true>();
+            LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
+#pragma unroll
+            for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
+        }
     }
 }
 
@@ -607,7 +677,7 @@ __global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a,
 // zeroed (simulation_object.rs:1076-1102), inverse FFT.  The unitary scales of
 // both 3-D transforms (1/N^3 in total, exact) ride on the Green's factor.
 template <int N>
-__global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_poisson_mid(PoisArgs a) {
+__global__ __launch_bounds__((Geom<N, 2>::THREADS)) MSM_OCC(N, 2) void k_poisson_mid(PoisArgs a) {
     using G = Geom<N, 2>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
@@ -618,6 +688,10 @@ __global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_poisson_mid(PoisArgs 
     const Tile<N, 2> t(blockIdx.x, threadIdx.x);
     cplx* tw = lds + G::LPW * G::LINE_LDS;
     load_twiddles<N, 2>(tw, a.tw);
+    // k_i^2 through LDS: sixteen global reads per thread would be hoisted above the transform and held in registers
+    __shared__ real kq[N];
+    for (int i = threadIdx.x; i < N; i += G::THREADS) kq[i] = a.ksq[i];
+    if constexpr (!G::USES_LDS) lds_barrier();   // otherwise the exchange barriers of the forward run lie in between
     cplx* line = lds + t.ln * G::LINE_LDS;
     cplx* __restrict__ w = a.W + (size_t)p * a.n3;
 
@@ -626,23 +700,25 @@ __global__ __launch_bounds__((Geom<N, 2>::THREADS)) void k_poisson_mid(PoisArgs 
     for (int q = 0; q < E; ++q) v[q] = w[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
     LineFft<real, N, -1>::run(v, t.j0, line, tw);
 
-    const real kxy = a.ksq[t.c1] + a.ksq[t.c2];
+    const real kxy = kq[t.c1] + kq[t.c2];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const real k2 = (kxy + a.ksq[t.j0 + TPL * q]) * a.fourpi2;
+        const real k2 = (kxy + kq[t.j0 + TPL * q]) * a.fourpi2;
         const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
         v[q] = cscale(v[q], g);
     }
     if constexpr (G::USES_LDS) lds_barrier();  // all exchange reads of the forward run are done
     LineFft<real, N, +1>::run(v, t.j0, line, tw);
+    // the store addresses are rebuilt here: kept alive since the loads they would cost 32 registers
+    const size_t sbase = (size_t)fresh((unsigned)t.base) + (size_t)fresh((unsigned)t.j0) * t.stride;
 #pragma unroll
-    for (int q = 0; q < E; ++q) w[t.base + (size_t)(t.j0 + TPL * q) * t.stride] = v[q];
+    for (int q = 0; q < E; ++q) w[sbase + (size_t)(TPL * q) * t.stride] = v[q];
 }
 
 // x pass, inverse: split phi_a / phi_b (real(phi), simulation_object.rs:1109) and/or
 // record this workgroup's max|phi| per stream (max_all(abs(phi)), :905).
 template <int N, int STOREPHI, int TRACKMAX>
-__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_phi_out(PoisArgs a) {
+__global__ __launch_bounds__((Geom<N, 0>::THREADS)) MSM_OCC(N, 0) void k_phi_out(PoisArgs a) {
     using G = Geom<N, 0>;
     constexpr int E = G::E, TPL = G::TPL;
     __shared__ cplx lds[G::LDS_ELEMS];
