@@ -2,18 +2,22 @@
 // translation unit (-DMSM_REAL=double|float -DMSM_SUFFIX=f64|f32).
 //
 // Device layout (per context):
-//   P[n_streams][N^3]  complex  the state: psi before the first step, psi_k
-//                               afterwards                 simulation_object.rs:57,60
+//   P[n_streams][N^3]  complex  the state: psi before the first step; afterwards psi_k
+//                               (simulation_object.rs:57,60) -- in the 256^3 engine its
+//                               half-inverted image S = pass A of psi, see kernels_two_pass.inc
 //   X[batch][N^3]      complex  psi of the current batch inside a step (scratch)
 //   W[batch/2][N^3]    complex  Poisson work array: two streams' densities
 //                               packed as re/im of one complex grid
 //   PHI[batch][N^3]    real     potential per stream     simulation_object.rs:63
-// A 3-D transform is three passes of the batched line FFT (fft_core.hpp), one
-// per axis, each moving every element once HBM -> registers -> HBM; all
-// pointwise operators of the step are applied inside a pass's load or store,
-// and neighbouring passes that work on the same lines are fused (forward z +
-// inverse z around the second drift; inverse x + density + Poisson forward x).
-// Between steps only psi_k is kept; psi is rebuilt on demand for downloads.
+// Three implementations of the same step share this file's host side:
+//   kernels_generic.inc   any power-of-two N <= 512: a 3-D transform is three passes of the batched line FFT
+//                         (fft_core.hpp), every pointwise operator applied inside a pass's load or store,
+//                         neighbouring passes on the same lines fused
+//   kernels_two_pass.inc  N = 256, 3-D: two passes per transform through a blocked intermediate layout
+//   kernels_unfused.inc   1-D / 2-D grids and edges that are not a power of two: whole transforms with one
+//                         kernel per pointwise operator (chirp-z lines for the odd sizes)
+// kernels_scalar.inc holds the per-stream bookkeeping kernels, sampling and reductions.
+// Between steps only one complex grid per stream is kept; psi is rebuilt on demand for downloads.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -253,1582 +257,10 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
     }
 }
 
-// Waves per SIMD at which a generic pass kernel fills the CU as far as its LDS tile allows: the register allocator is
-// told to stay within 512 / that many VGPRs, so that the workgroups the LDS admits really are resident together
-// (in single precision the tiles are half as large and the kernels otherwise settle on one workgroup per CU).
-template <int N, int AX>
-constexpr int occ_waves() {
-    using G = Geom<N, AX>;
-    const int bytes = (int)(G::LDS_ELEMS * sizeof(cplx)) + 4096;      // tile + twiddles + reduction scratch
-    const int wpw = G::THREADS >= 64 ? G::THREADS / 64 : 1;          // waves per workgroup
-    int wgs = 163840 / bytes;
-    if (wgs > 32 / wpw) wgs = 32 / wpw;
-    if (wgs < 1) wgs = 1;
-    int w = wgs * wpw / 4;
-    return w < 1 ? 1 : (w > 4 ? 4 : w);
-}
-#define MSM_OCC(N, AX) __attribute__((amdgpu_waves_per_eu(occ_waves<N, AX>())))
-
-// ---------------------------------------------------------------------------
-// generic axis pass: transforms of psi / psi_k and the plain passes on W
-// ---------------------------------------------------------------------------
-struct PsiArgs {
-    const cplx* src;
-    cplx* dst;
-    size_t n3;
-    const int* active;   // may be null
-    int s0;              // first (global) stream of this launch
-    int src_local;       // 1: src is indexed by blockIdx.y (batch scratch), 0: by the global stream id
-    int dst_local;
-    int pair_nb;         // > 0: blockIdx.y is a PAIR index over nb streams (W passes)
-    int nlines;          // x passes: number of lines of the grid (a 1-D grid has fewer than one tile); 0 = no limit
-    const cplx* tw;
-    const cplx* drift;   // [n_streams][N]
-    const real* phi;     // [batch][n3], local stream index
-    const real* kick;    // [n_streams]
-    real scale;
-};
-
-// LOAD: 0 plain, 1 multiply by the drift table at the line position (simulation_object.rs:504-516),
-//       2 kick psi *= exp(i kick phi)                                 (simulation_object.rs:535-545)
-// STORE: 0 scale only, 1 drift table times scale                      (simulation_object.rs:562-574)
-template <int N, int SGN, int AX, int LOAD, int STORE>
-__global__ __launch_bounds__((Geom<N, AX>::THREADS)) MSM_OCC(N, AX) void k_psi_pass(PsiArgs a) {
-    using G = Geom<N, AX>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-
-    const int ls = blockIdx.y;
-    const int sg = a.s0 + ls;  // global stream id (per-stream tables, activity)
-    int si = a.src_local ? ls : sg, di = a.dst_local ? ls : sg;
-    if (a.pair_nb > 0) {
-        const int sa = a.s0 + 2 * ls, sb = sa + 1;
-        const bool act = a.active == nullptr || a.active[sa] || (2 * ls + 1 < a.pair_nb && a.active[sb]);
-        if (!act) return;
-        si = di = ls;  // W is indexed by the local pair
-    } else if (a.active != nullptr && !a.active[sg]) {
-        return;
-    }
-
-    const Tile<N, AX> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, AX>(tw, a.tw);
-    cplx* line = lds + t.ln * G::LINE_LDS;
-
-    const cplx* __restrict__ src = a.src + (size_t)si * a.n3;
-    cplx* __restrict__ dst = a.dst + (size_t)di * a.n3;
-
-    // a tile past the end of a small grid (x passes of 1-D grids): its threads transform zeros and store nothing
-    const bool valid = AX != 0 || a.nlines == 0 || (int)(blockIdx.x * G::LPW + t.ln) < a.nlines;
-    cplx v[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = valid ? src[t.base + (size_t)(t.j0 + TPL * q) * t.stride] : mk<real>(0, 0);
-
-    if constexpr (LOAD == 1) {
-        const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-    } else if constexpr (LOAD == 2) {
-        const real* __restrict__ phi = a.phi + (size_t)ls * a.n3;
-        const real kc = a.kick[sg];
-        real ph[E];
-#pragma unroll
-        for (int q = 0; q < E; ++q) ph[q] = valid ? phi[t.base + (size_t)(t.j0 + TPL * q) * t.stride] : (real)0;
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            real sn, cs;
-            sincos_t(kc * ph[q], &sn, &cs);
-            v[q] = cmul(v[q], mk<real>(cs, sn));
-        }
-    }
-
-    LineFft<real, N, SGN, AX == 0>::run(v, t.j0, line, tw);
-
-    if (valid) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const int pos = t.j0 + TPL * q;
-            cplx val = v[q];
-            if constexpr (STORE >= 1) val = cmul(val, a.drift[(size_t)sg * N + pos]);
-            dst[t.base + (size_t)pos * t.stride] = cscale(val, a.scale);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// fused z pass around the second kinetic half-step:
-//   psi_k = D_z F_z[.] / N^{3/2}   -> stored (the state carried to the next step), aliased-mass sum,
-//   then straight on with F_z^{-1} of the same lines (first pass of psi = F^-1 psi_k).
-// (simulation_object.rs:552-581 and check_alias :1249-1280.)  Saves one read of psi_k.
-// ---------------------------------------------------------------------------
-struct FzArgs {
-    const cplx* X;       // [batch][n3] local: input (x and y already transformed) and output
-    cplx* Xout;
-    cplx* P;             // [n_streams][n3] global: psi_k
-    size_t n3;
-    const int* active;
-    int s0;
-    const cplx* tw;
-    const cplx* drift;
-    real scale;          // 1 / N^{dims/2}
-    const real* ksq;
-    real alias_cut, fourpi2;
-    double* partial;     // [n_streams][ntiles]
-    int ntiles;
-};
-
-template <int N>
-__global__ __launch_bounds__((Geom<N, 2>::THREADS)) MSM_OCC(N, 2) void k_fwdz_invz(FzArgs a) {
-    using G = Geom<N, 2>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-    __shared__ double red[G::THREADS];
-
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    const Tile<N, 2> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, 2>(tw, a.tw);
-    cplx* line = lds + t.ln * G::LINE_LDS;
-    const cplx* __restrict__ x = a.X + (size_t)ls * a.n3;
-    cplx* __restrict__ xo = a.Xout + (size_t)ls * a.n3;
-    cplx* __restrict__ pk = a.P + (size_t)sg * a.n3;
-    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-
-    cplx v[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = x[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
-    LineFft<real, N, -1>::run(v, t.j0, line, tw);
-
-    const real kxy = a.ksq[t.c1] + a.ksq[t.c2];  // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
-    double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const int pos = t.j0 + TPL * q;
-        v[q] = cscale(cmul(v[q], d[pos]), a.scale);
-        pk[t.base + (size_t)pos * t.stride] = v[q];
-        const real k2 = (kxy + a.ksq[pos]) * a.fourpi2;
-        if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
-    }
-    const double tot = block_sum<G::THREADS>(acc, red);   // also orders the LDS reuse below
-    if (threadIdx.x == 0) a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
-
-    LineFft<real, N, +1>::run(v, t.j0, line, tw);
-#pragma unroll
-    for (int q = 0; q < E; ++q) xo[t.base + (size_t)(t.j0 + TPL * q) * t.stride] = v[q];
-}
-
-// ---------------------------------------------------------------------------
-// Poisson solve (calculate_potential, simulation_object.rs:1066-1110) on
-// stream pairs: rho_a + i rho_b is transformed as one complex grid; the
-// Green's function is real and even, so the inverse returns phi_a + i phi_b.
-// ---------------------------------------------------------------------------
-struct PoisArgs {
-    const cplx* X;       // psi, [.][n3]
-    cplx* Xout;          // where the fused inverse pass stores psi (may alias X)
-    int x_local;         // 1: X is the batch scratch (local index), 0: the per-stream state
-    cplx* W;             // [pairs][n3]
-    real* PHI;           // [batch][n3]
-    size_t n3;
-    const int* active;
-    int s0, nb;
-    const cplx* tw;
-    const cplx* drift;
-    const real* ksq;
-    real mass_factor, pois_c, fourpi2, inv_n3, scale;
-    double* partial;     // [n_streams][ntiles] per-workgroup max|phi|
-    int ntiles;
-    double* dens;        // optional [n3]: += sum over streams |psi|^2
-};
-
-// x pass, forward, from a stored psi: rho = M |psi|^2 of both streams of the pair
-// (calculate_density, simulation_object.rs:1031-1063).
-template <int N>
-__global__ __launch_bounds__((Geom<N, 0>::THREADS)) MSM_OCC(N, 0) void k_rho_pass(PoisArgs a) {
-    using G = Geom<N, 0>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    const bool has_b = (2 * p + 1 < a.nb);
-    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
-
-    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, 0>(tw, a.tw);
-    cplx* line = lds + t.ln * G::LINE_LDS;
-
-    const cplx* __restrict__ xa = a.X + (size_t)(a.x_local ? 2 * p : sa) * a.n3;
-    const cplx* __restrict__ xb = a.X + (size_t)(a.x_local ? 2 * p + 1 : sb) * a.n3;
-    cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-
-    cplx v[E];
-    if (has_b) {
-        cplx va[E], vb[E];
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            va[q] = xa[t.base + t.j0 + TPL * q];
-            vb[q] = xb[t.base + t.j0 + TPL * q];
-        }
-#pragma unroll
-        for (int q = 0; q < E; ++q)
-            v[q] = mk<real>(a.mass_factor * (va[q].x * va[q].x + va[q].y * va[q].y),
-                            a.mass_factor * (vb[q].x * vb[q].x + vb[q].y * vb[q].y));
-    } else {
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const cplx va = xa[t.base + t.j0 + TPL * q];
-            v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), (real)0);
-        }
-    }
-    LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
-#pragma unroll
-    for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
-}
-
-// Last pass of psi = F^-1[...] (along x) fused with the first pass of the Poisson solve:
-// for every pair of the batch, finish psi_a and psi_b (drift factor, inverse x transform, unitary
-// scale), optionally store them, form rho_a + i rho_b in registers and transform it along x into W.
-// One workgroup owns one tile of lines for ALL pairs, so the optional ensemble density
-// sum_s |psi_s|^2 is accumulated in registers and added to `dens` without atomics.
-template <int N, int DRIFT, int STOREPSI, int DENS>
-__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_invx_rho(PoisArgs a) {
-    using G = Geom<N, 0>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-
-    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, 0>(tw, a.tw);
-    cplx* line = lds + t.ln * G::LINE_LDS;
-
-    double dacc[DENS ? E : 1];
-    if constexpr (DENS) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) dacc[q] = 0.0;
-    }
-    const int pairs = (a.nb + 1) / 2;
-    for (int p = 0; p < pairs; ++p) {
-        const int sa = a.s0 + 2 * p, sb = sa + 1;
-        const bool act_a = a.active[sa] != 0;
-        const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
-        if (!act_a && !act_b) continue;   // uniform over the workgroup
-        real rho[2][E];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool act = h == 0 ? act_a : act_b;
-            if (act) {
-                const int sg = h == 0 ? sa : sb;
-                const cplx* __restrict__ x = a.X + (size_t)(2 * p + h) * a.n3;
-                cplx v[E];
-#pragma unroll
-                for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
-                if constexpr (DRIFT) {
-                    const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-#pragma unroll
-                    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-                }
-                LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
-                cplx* __restrict__ xo = a.Xout + (size_t)(2 * p + h) * a.n3;
-#pragma unroll
-                for (int q = 0; q < E; ++q) {
-                    v[q] = cscale(v[q], a.scale);
-                    if constexpr (STOREPSI) xo[t.base + t.j0 + TPL * q] = v[q];
-                    const real m2 = v[q].x * v[q].x + v[q].y * v[q].y;
-                    rho[h][q] = a.mass_factor * m2;
-                    if constexpr (DENS) dacc[q] += (double)m2;
-                }
-                if constexpr (G::USES_LDS) exch_sync<true>();   // exchange reads done before the next run writes
-            } else {
-#pragma unroll
-                for (int q = 0; q < E; ++q) rho[h][q] = (real)0;
-            }
-        }
-        cplx v[E];
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = mk<real>(rho[0][q], rho[1][q]);
-        LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
-        cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-#pragma unroll
-        for (int q = 0; q < E; ++q) w[t.base + t.j0 + TPL * q] = v[q];
-        if constexpr (G::USES_LDS) exch_sync<true>();
-    }
-    if constexpr (DENS) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];
-    }
-}
-
-// Kick pass, fused with the last pass of the Poisson solve and the first pass of psi_k = F[psi]:
-// per pair, phi_a + i phi_b = F_x^-1[W] stays in registers; then for each stream the half-drifted
-// psi is rebuilt from the y-transformed scratch exactly as k_invx_rho formed it (drift factor,
-// inverse x, unitary scale), kicked psi *= exp(i kick phi) (simulation_object.rs:535-545),
-// transformed forward along x and stored with the second drift's x factor (:562-574).
-// Neither phi nor the half-drifted psi ever goes to HBM.
-template <int N>
-__global__ __launch_bounds__((Geom<N, 0>::THREADS)) void k_kick_fwdx(PoisArgs a, const real* __restrict__ kick) {
-    using G = Geom<N, 0>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    const bool act_a = a.active[sa] != 0;
-    const bool act_b = (2 * p + 1 < a.nb) && a.active[sb] != 0;
-    if (!act_a && !act_b) return;
-
-    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, 0>(tw, a.tw);
-    cplx* line = lds + t.ln * G::LINE_LDS;
-
-    if constexpr (sizeof(real) == 4) {
-        // Single precision has the registers to let the loads run ahead of their use (one 8-wave workgroup per CU would
-        // otherwise wait out every load): psi_a is fetched together with W, psi_b before psi_a is worked on.  A finished
-        // (or absent) stream of the pair is still transformed -- its scratch slot exists -- and only its store is skipped,
-        // so that the code is one straight line.
-        const int sbs = (2 * p + 1 < a.nb) ? sb : sa;               // tables of an absent partner: any valid row
-        cplx* __restrict__ xa = a.Xout + (size_t)(2 * p) * a.n3;
-        cplx* __restrict__ xb = a.Xout + (size_t)(2 * p + 1) * a.n3;
-        const cplx* __restrict__ da = a.drift + (size_t)sa * N;
-        const cplx* __restrict__ db = a.drift + (size_t)sbs * N;
-        const real kca = kick[sa], kcb = kick[sbs];
-        real phi[2][E];
-        cplx va[E], vb[E];
-        {
-            const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-            cplx vw[E];
-#pragma unroll
-            for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
-#pragma unroll
-            for (int q = 0; q < E; ++q) va[q] = xa[t.base + t.j0 + TPL * q];
-            LineFft<real, N, +1, true>::run(vw, t.j0, line, tw);
-#pragma unroll
-            for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
-        }
-        auto one = [&](cplx (&v)[E], const cplx* __restrict__ d, real kc, const real (&ph)[E]) {
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-            if constexpr (G::USES_LDS) exch_sync<true>();
-            LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
-#pragma unroll
-            for (int q = 0; q < E; ++q) {
-                real sn, cs;
-                sincos_t(kc * ph[q], &sn, &cs);
-                v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
-            }
-            if constexpr (G::USES_LDS) exch_sync<true>();
-            LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-        };
-#pragma unroll
-        for (int q = 0; q < E; ++q) vb[q] = xb[t.base + t.j0 + TPL * q];
-        one(va, da, kca, phi[0]);
-        if (act_a) {
-#pragma unroll
-            for (int q = 0; q < E; ++q) xa[t.base + t.j0 + TPL * q] = va[q];
-        }
-        one(vb, db, kcb, phi[1]);
-        if (act_b) {
-#pragma unroll
-            for (int q = 0; q < E; ++q) xb[t.base + t.j0 + TPL * q] = vb[q];
-        }
-    } else {
-        real phi[2][E];
-        {
-            const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-            cplx vw[E];
-#pragma unroll
-            for (int q = 0; q < E; ++q) vw[q] = w[t.base + t.j0 + TPL * q];
-            LineFft<real, N, +1, true>::run(vw, t.j0, line, tw);
-#pragma unroll
-            for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool act = h == 0 ? act_a : act_b;
-            if (!act) continue;   // uniform over the workgroup
-            const int sg = h == 0 ? sa : sb;
-            cplx* __restrict__ x = a.Xout + (size_t)(2 * p + h) * a.n3;
-            const cplx* __restrict__ d = a.drift + (size_t)sg * N;
-            const real kc = kick[sg];
-            if constexpr (G::USES_LDS) exch_sync<true>();   // also keeps the psi loads below the previous transform
-            cplx v[E];
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = x[t.base + t.j0 + TPL * q];
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = cmul(v[q], d[t.j0 + TPL * q]);
-            LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
-#pragma unroll
-            for (int q = 0; q < E; ++q) {
-                real sn, cs;
-                sincos_t(kc * phi[h][q], &sn, &cs);
-                v[q] = cmul(cscale(v[q], a.scale), mk<real>(cs, sn));
-            }
-            if constexpr (G::USES_LDS) exch_sync<true>();
-            LineFft<real, N, -1, true>::run(v, t.j0, line, tw);
-#pragma unroll
-            for (int q = 0; q < E; ++q) x[t.base + t.j0 + TPL * q] = cmul(v[q], d[t.j0 + TPL * q]);
-        }
-    }
-}
-
-// z pass, fused: forward FFT, Green's multiply -C / k^2 with the k = 0 mode
-// zeroed (simulation_object.rs:1076-1102), inverse FFT.  The unitary scales of
-// both 3-D transforms (1/N^3 in total, exact) ride on the Green's factor.
-template <int N>
-__global__ __launch_bounds__((Geom<N, 2>::THREADS)) MSM_OCC(N, 2) void k_poisson_mid(PoisArgs a) {
-    using G = Geom<N, 2>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
-
-    const Tile<N, 2> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, 2>(tw, a.tw);
-    // k_i^2 through LDS: sixteen global reads per thread would be hoisted above the transform and held in registers
-    __shared__ real kq[N];
-    for (int i = threadIdx.x; i < N; i += G::THREADS) kq[i] = a.ksq[i];
-    if constexpr (!G::USES_LDS) lds_barrier();   // otherwise the exchange barriers of the forward run lie in between
-    cplx* line = lds + t.ln * G::LINE_LDS;
-    cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-
-    cplx v[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = w[t.base + (size_t)(t.j0 + TPL * q) * t.stride];
-    LineFft<real, N, -1>::run(v, t.j0, line, tw);
-
-    const real kxy = kq[t.c1] + kq[t.c2];
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const real k2 = (kxy + kq[t.j0 + TPL * q]) * a.fourpi2;
-        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
-        v[q] = cscale(v[q], g);
-    }
-    if constexpr (G::USES_LDS) lds_barrier();  // all exchange reads of the forward run are done
-    LineFft<real, N, +1>::run(v, t.j0, line, tw);
-    // the store addresses are rebuilt here: kept alive since the loads they would cost 32 registers
-    const size_t sbase = (size_t)fresh((unsigned)t.base) + (size_t)fresh((unsigned)t.j0) * t.stride;
-#pragma unroll
-    for (int q = 0; q < E; ++q) w[sbase + (size_t)(TPL * q) * t.stride] = v[q];
-}
-
-// x pass, inverse: split phi_a / phi_b (real(phi), simulation_object.rs:1109) and/or
-// record this workgroup's max|phi| per stream (max_all(abs(phi)), :905).
-template <int N, int STOREPHI, int TRACKMAX>
-__global__ __launch_bounds__((Geom<N, 0>::THREADS)) MSM_OCC(N, 0) void k_phi_out(PoisArgs a) {
-    using G = Geom<N, 0>;
-    constexpr int E = G::E, TPL = G::TPL;
-    __shared__ cplx lds[G::LDS_ELEMS];
-    __shared__ double red[TRACKMAX ? 32 : 1];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    const bool has_b = (2 * p + 1 < a.nb);
-    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
-
-    const Tile<N, 0> t(blockIdx.x, threadIdx.x);
-    cplx* tw = lds + G::LPW * G::LINE_LDS;
-    load_twiddles<N, 0>(tw, a.tw);
-    cplx* line = lds + t.ln * G::LINE_LDS;
-    const cplx* __restrict__ w = a.W + (size_t)p * a.n3;
-
-    cplx v[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = w[t.base + t.j0 + TPL * q];
-    LineFft<real, N, +1, true>::run(v, t.j0, line, tw);
-
-    real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
-    real* __restrict__ pb = a.PHI + (size_t)(2 * p + 1) * a.n3;
-    double ma = 0.0, mb = 0.0;
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const size_t g = t.base + t.j0 + TPL * q;
-        if constexpr (STOREPHI) {
-            pa[g] = v[q].x;
-            if (has_b) pb[g] = v[q].y;
-        }
-        if constexpr (TRACKMAX) {
-            const double ax = fabs((double)v[q].x), ay = fabs((double)v[q].y);
-            ma = (ax != ax) ? ax : ((ma != ma) ? ma : (ax > ma ? ax : ma));
-            mb = (ay != ay) ? ay : ((mb != mb) ? mb : (ay > mb ? ay : mb));
-        }
-    }
-    if constexpr (TRACKMAX) {
-        block_max2<G::THREADS>(ma, mb, red);
-        if (threadIdx.x == 0) {
-            a.partial[(size_t)sa * a.ntiles + blockIdx.x] = ma;
-            if (has_b) a.partial[(size_t)sb * a.ntiles + blockIdx.x] = mb;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Two-pass Poisson solve for N = 256 (y split as 16 x 16):
-//   pass A  (x lines and the outer radix-16 stage of y) lives inside the x-pass kernels of psi,
-//   pass B  (inner radix-16 stage of y, all of z, Green's multiply, and back) is one kernel,
-// so the pair-packed work array crosses HBM twice per solve instead of four times.
-// With y = b + 16 t, ky = t' + 16 b':  F_y = DFT16_b[ w^(b t') DFT16_t[.] ],  w = e^(-2 pi i / 256).
-// An A tile is 32 x-lines: 16 rows y = b + 16 t of the two planes z = 2 zh + zl.  Between the passes
-// a grid is stored as
-//     T[t'][kx >> 4][b][zh][(kx >> 2) & 3][kx bit 1][zl][kx bit 0]
-// The innermost 8 elements (128 B) are what an A tile and a B run have in common.  Four such blocks
-// with neighbouring kx sit side by side: an A tile (fixed b, zh; all t', kx) moves 512-byte pieces,
-// a B run (fixed t', kx >> 2; all b, z) moves 128-byte pieces 512 B apart whose neighbours belong to
-// the next three runs, i.e. to workgroups in flight at the same time.  Measured as plain copies this
-// split serves both sides at 5.0 / 5.7 TB/s; fully contiguous B runs left the A side at 3.8 TB/s.
-// ---------------------------------------------------------------------------
-namespace tp {
-constexpr int N = 256;
-constexpr int A_THREADS = 512, A_LINE = Geom<N, 0>::LINE_LDS;
-constexpr int A_HALF = 16 * A_LINE + 8;            // zl = 1 lines start 128 B off the bank period of zl = 0
-constexpr int A_LDS = 2 * A_HALF + N;              // + twiddle table
-constexpr int A_TILES = 2048;                      // zh (128) x b (16)
-constexpr size_t T_TP = (size_t)64 * 16384;        // stride of t' in T (elements)
-constexpr int B_THREADS = 1024;                    // one workgroup per run (t', kx >> 2): 16 b x 256 z x 4 kx
-constexpr int B_LINE = 272;                        // reals per padded z line; 272 = 16 mod 32 keeps line pairs on disjoint banks
-constexpr int B_LINES = 64;                        // z lines per workgroup: 16 b' x 4 kx
-constexpr int B_PLANE = B_LINES * B_LINE + 8;
-constexpr int B_BLOCKS = 1024;                     // runs per grid
-constexpr int KL = 4;                              // 128-byte blocks of neighbouring kx side by side in T
-constexpr size_t T_B = (size_t)128 * KL * 8;       // stride of b in T (elements)
-constexpr int MAX_BATCH = 256;                     // streams per sub-batch the A kernels keep flags for
-}
-
-struct TileA {
-    int j0, zl, t, b, zh;
-    size_t base;     // first element of this thread's x line in the natural layout
-    cplx* line;      // its padded LDS line
-    __device__ __forceinline__ TileA(int tile, int tid, cplx* lds) {
-        j0 = tid & 15;
-        const int ln = tid >> 4;
-        zl = ln >> 4; t = ln & 15;
-        zh = tile >> 4; b = tile & 15;
-        base = ((size_t)(2 * zh + zl) * tp::N + (b + 16 * t)) * tp::N;
-        line = lds + zl * tp::A_HALF + t * tp::A_LINE;
-    }
-};
-
-// Line role (thread = 16 kx of one line) -> column role (thread = one (kx, zl), the 16 lines t),
-// radix-16 stage over t, store to T.  Barriers inside; all 512 threads call.
-__device__ __forceinline__ void a_store_T(cplx (&v)[16], const TileA& t, cplx* lds, cplx* __restrict__ wT, size_t grid_off) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.line[lds_pad(t.j0 + 16 * q)] = v[q];   // own line: ordered within the wave
-    lds_barrier();
-    const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
-    const cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = col[q * tp::A_LINE];
-    dft<16, -1, real>(v);
-    const unsigned off = (unsigned)(((((kxh / tp::KL) * 16 + t.b) * 128 + t.zh) * tp::KL + (kxh % tp::KL)) * 8 + (tid & 7));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) (wT + (grid_off + (size_t)q * tp::T_TP))[off] = v[q];
-}
-
-// The way back, in two halves so that the loads can be issued ahead of their use: a_fetch_T only
-// loads (column role); a_cols_to_lines does the inverse radix-16 stage over t' and the column role ->
-// line role exchange (one barrier; LDS lines must not be in use by other wavefronts on entry).
-// The sixteen loads lie 16 MiB apart; one running address pair serves them all.
-typedef real real2v __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) real2v* gcptr;
-__device__ __forceinline__ void a_fetch_T(cplx (&v)[16], const TileA& t, const cplx* __restrict__ wT, size_t grid_off) {
-    const int tid = threadIdx.x;
-    const int kxh = tid >> 3;
-    gcptr p = (gcptr)(wT + grid_off + (size_t)(((((kxh / tp::KL) * 16 + t.b) * 128 + t.zh) * tp::KL + (kxh % tp::KL)) * 8 + (tid & 7)));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const real2v d = *p;
-        v[q] = mk<real>(d.x, d.y);
-        p += tp::T_TP;
-        asm volatile("" : "+v"(p));
-    }
-}
-__device__ __forceinline__ void a_cols_to_lines(cplx (&v)[16], const TileA& t, cplx* lds) {
-    const int tid = threadIdx.x;
-    const int kxh = tid >> 3, zl = (tid >> 1) & 1, kx = (kxh << 2) | (((tid >> 2) & 1) << 1) | (tid & 1);
-    dft<16, +1, real>(v);
-    cplx* col = lds + zl * tp::A_HALF + lds_pad(kx);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) col[q * tp::A_LINE] = v[q];
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = t.line[lds_pad(t.j0 + 16 * q)];
-}
-__device__ __forceinline__ void a_load_T(cplx (&v)[16], const TileA& t, cplx* lds, const cplx* __restrict__ wT, size_t grid_off) {
-    a_fetch_T(v, t, wT, grid_off);
-    a_cols_to_lines(v, t, lds);
-}
-
-__device__ __forceinline__ void a_load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
-    if (threadIdx.x < tp::N) tw_lds[threadIdx.x] = tw_g[TwLayout<tp::N>::source(threadIdx.x)];
-    lds_barrier();
-}
-
-// rho from a stored psi on A tiles (first step, msm_potential).
-__global__ __launch_bounds__(tp::A_THREADS) void k_rho_pass2(PoisArgs a) {
-    constexpr int N = tp::N, E = 16, TPL = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    const bool has_b = (2 * p + 1 < a.nb);
-    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-    const cplx* __restrict__ xa = a.X + (size_t)(a.x_local ? 2 * p : sa) * a.n3;
-    const cplx* __restrict__ xb = a.X + (size_t)(a.x_local ? 2 * p + 1 : sb) * a.n3;
-    cplx v[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const cplx va = xa[t.base + t.j0 + TPL * q];
-        real rb = (real)0;
-        if (has_b) {
-            const cplx vb = xb[t.base + t.j0 + TPL * q];
-            rb = a.mass_factor * (vb.x * vb.x + vb.y * vb.y);
-        }
-        v[q] = mk<real>(a.mass_factor * (va.x * va.x + va.y * va.y), rb);
-    }
-    LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
-    a_store_T(v, t, lds, a.W, (size_t)p * a.n3);
-}
-
-// k_phi_out on A tiles.
-template <int STOREPHI, int TRACKMAX>
-__global__ __launch_bounds__(tp::A_THREADS) void k_phi_out2(PoisArgs a) {
-    constexpr int N = tp::N, E = 16, TPL = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    __shared__ double red[TRACKMAX ? 32 : 1];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    const bool has_b = (2 * p + 1 < a.nb);
-    if (!(a.active[sa] || (has_b && a.active[sb]))) return;
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-    cplx v[E];
-    a_load_T(v, t, lds, a.W, (size_t)p * a.n3);
-    LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
-
-    real* __restrict__ pa = a.PHI + (size_t)(2 * p) * a.n3;
-    real* __restrict__ pb = a.PHI + (size_t)(2 * p + 1) * a.n3;
-    double ma = 0.0, mb = 0.0;
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const size_t g = t.base + t.j0 + TPL * q;
-        if constexpr (STOREPHI) {
-            pa[g] = v[q].x;
-            if (has_b) pb[g] = v[q].y;
-        }
-        if constexpr (TRACKMAX) {
-            ma = nanmax(fabs((double)v[q].x), ma);
-            mb = nanmax(fabs((double)v[q].y), mb);
-        }
-    }
-    if constexpr (TRACKMAX) {
-        block_max2<tp::A_THREADS>(ma, mb, red);
-        if (threadIdx.x == 0) {
-            a.partial[(size_t)sa * a.ntiles + blockIdx.x] = ma;
-            if (has_b) a.partial[(size_t)sb * a.ntiles + blockIdx.x] = mb;
-        }
-    }
-}
-
-// max|phi| only (the potential that sizes the next timestep, simulation_object.rs:497,905): one workgroup
-// owns a tile for all pairs of the batch and fetches the next pair's tile while it transforms the
-// current one (straight-line body, stream flags in LDS: see k_invx_rho3).
-__global__ __launch_bounds__(tp::A_THREADS) void k_phi_max3(PoisArgs a) {
-    constexpr int N = tp::N, E = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    __shared__ double red[32];
-    __shared__ int act_lds[tp::MAX_BATCH + 2];
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    for (int i = threadIdx.x; i < tp::MAX_BATCH + 2; i += tp::A_THREADS) act_lds[i] = (i < a.nb) ? a.active[a.s0 + i] : 0;
-    a_load_twiddles(tw, a.tw);   // barrier inside
-    const int pairs = (a.nb + 1) / 2;
-    cplx va[E], vb[E];
-    a_fetch_T(va, t, a.W, 0);
-    auto one = [&](cplx (&v)[E], int p) {
-        const bool act_a = act_lds[2 * p] != 0, act_b = act_lds[2 * p + 1] != 0;
-        a_cols_to_lines(v, t, lds);
-        LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
-        double ma = 0.0, mb = 0.0;
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            ma = nanmax(fabs((double)v[q].x), ma);
-            mb = nanmax(fabs((double)v[q].y), mb);
-        }
-        block_max2<tp::A_THREADS>(ma, mb, red);   // its barrier also separates this exchange from the next column writes
-        if (threadIdx.x == 0) {
-            if (act_a) a.partial[(size_t)(a.s0 + 2 * p) * a.ntiles + blockIdx.x] = ma;
-            if (act_b) a.partial[(size_t)(a.s0 + 2 * p + 1) * a.ntiles + blockIdx.x] = mb;
-        }
-        lds_barrier();   // red[] is reused by the next pair
-    };
-    for (int p = 0; p < pairs; p += 2) {
-        a_fetch_T(vb, t, a.W, (size_t)min(p + 1, pairs - 1) * a.n3);
-        one(va, p);
-        a_fetch_T(va, t, a.W, (size_t)min(p + 2, pairs - 1) * a.n3);
-        if (p + 1 < pairs) one(vb, p + 1);
-    }
-}
-
-// Pass-B role changes through one real LDS plane (32 padded z lines).
-//   column role: thread = (z = tid >> 1, kx bit 0 = tid & 1), holds the 16 values b (or b')
-//   line role:   thread = (j0 = tid & 15, line L = tid >> 4 = 2 b' + kx bit 0), holds z = j0 + 16 q
-struct RolesB {
-    int j0, L, bprime, kxl;   // line role: z = j0 + 16 q of line L = (b', kx low bits kxl)
-    real* colw;
-    real* line;
-    // Lines are stored as L = (kx bit 1) * 32 + 2 b' + (kx bit 0); the upper half is skewed by 8 reals
-    // so that the four kx of a column access fall on distinct bank quarters.
-    static __device__ __forceinline__ int line_off(int L) { return L * tp::B_LINE + (L >> 5) * 8; }
-    __device__ __forceinline__ RolesB(real* plane) {
-        const int tid = threadIdx.x;
-        j0 = tid & 15; L = tid >> 4;
-        line = plane + line_off(L);
-        bprime = (L >> 1) & 15; kxl = ((L >> 5) << 1) | (L & 1);
-        // column role: the lane's position in the 8-element block is (kx bit 1, zl, kx bit 0), zh = tid >> 3
-        const int inner = tid & 7, z = 2 * (tid >> 3) + ((inner >> 1) & 1);
-        colw = plane + line_off((inner >> 2) * 32 + (inner & 1)) + lds_pad(z);
-    }
-};
-// column -> line; the plane must be free on entry and is free again on return
-__device__ __forceinline__ void b_to_lines(cplx (&v)[16], const RolesB& r) {
-    constexpr int CS = 2 * tp::B_LINE;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r.colw[q * CS] = v[q].x;
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].x = r.line[lds_pad(r.j0 + 16 * q)];
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r.colw[q * CS] = v[q].y;
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].y = r.line[lds_pad(r.j0 + 16 * q)];
-}
-// line -> column; the plane must be free on entry; other threads may still read it on return
-__device__ __forceinline__ void b_to_cols(cplx (&v)[16], const RolesB& r) {
-    constexpr int CS = 2 * tp::B_LINE;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r.line[lds_pad(r.j0 + 16 * q)] = v[q].x;
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].x = r.colw[q * CS];
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r.line[lds_pad(r.j0 + 16 * q)] = v[q].y;
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q].y = r.colw[q * CS];
-}
-// blockIdx.x = run = (t', kx >> 2); neighbouring runs interleave in memory and run side by side
-struct RunB {
-    int run, tpi, kxh;
-    size_t off;       // first element of this run within a grid
-    unsigned toff;    // this lane's element within it (column role): (zh, position in the block)
-    __device__ __forceinline__ RunB() {
-        const int tid = threadIdx.x;
-        run = blockIdx.x; tpi = run >> 6; kxh = run & 63;
-        off = (size_t)(tpi * (64 / tp::KL) + kxh / tp::KL) * 16 * tp::T_B + (kxh % tp::KL) * 8;
-        toff = (unsigned)((tid >> 3) * (tp::KL * 8) + (tid & 7));
-    }
-    __device__ __forceinline__ int kx(const RolesB& r) const { return (kxh << 2) | r.kxl; }
-    __device__ __forceinline__ int ky(const RolesB& r) const { return tpi + 16 * r.bprime; }
-};
-// T (column role) -> inner y stage -> line role -> z transform; v ends as kz = j0 + 16 q
-__device__ __forceinline__ void b_forward(cplx (&v)[16], const cplx* __restrict__ T, size_t trun, unsigned toff,
-                                          int tpi, const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
-    const bufdesc rs = buf_of(T + trun);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) buf_ld(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * tp::T_B * sizeof(cplx)));
-#pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
-    dft<16, -1, real>(v);
-    b_to_lines(v, r);
-    LineFftSplit<real, tp::N, -1, true>::run(v, r.j0, r.line, tw_lds);
-}
-// the way back; the plane must be free on entry
-__device__ __forceinline__ void b_inverse(cplx (&v)[16], cplx* __restrict__ T, size_t trun, unsigned toff, int tpi,
-                                          const RolesB& r, const cplx* tw_lds, const cplx* __restrict__ tw_g) {
-    LineFftSplit<real, tp::N, +1, true>::run(v, r.j0, r.line, tw_lds);
-    b_to_cols(v, r);
-    dft<16, +1, real>(v);
-#pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], tw_g[(q * tpi) & (tp::N - 1)]);
-    const bufdesc rs = buf_of(T + trun);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) buf_st(v[q], rs, toff * (unsigned)sizeof(cplx), (unsigned)(q * tp::T_B * sizeof(cplx)));
-}
-
-// Pass B of the Poisson solve: inner y stage, z transform, Green's multiply -C / k^2 (k = 0 zeroed,
-// simulation_object.rs:1076-1102), and both stages back, on one run of T in place.
-__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_poisson_b(PoisArgs a) {
-    constexpr int N = tp::N;
-    __shared__ real plane[tp::B_PLANE];
-    __shared__ cplx tw[N];
-    const int tid = threadIdx.x;
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p, sb = sa + 1;
-    if (!(a.active[sa] || (2 * p + 1 < a.nb && a.active[sb]))) return;
-    __shared__ real kq[N];
-    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];   // first reads are behind the exchange barriers
-    else if (tid < 2 * N) kq[tid - N] = a.ksq[tid - N];
-    const RunB rb;
-    const RolesB r(plane);
-    const size_t trun = (size_t)p * a.n3 + rb.off;
-    const unsigned toff = rb.toff;
-
-    cplx v[16];
-    b_forward(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
-    const int kx = rb.kx(r), ky = rb.ky(r);
-    const real kxy = kq[kx] + kq[ky];   // ((kx^2 + ky^2) + kz^2) * (2 pi)^2, utils/fft.rs:140-160
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const real k2 = (kxy + kq[r.j0 + 16 * q]) * a.fourpi2;
-        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n3;
-        v[q] = cscale(v[q], g);
-    }
-    b_inverse(v, a.W, trun, toff, rb.tpi, r, tw, a.tw);
-}
-
-// Pass B of the psi transforms.  Between steps a stream's state is S = pass A of psi (psi after the forward x
-// lines and the outer y stage, in the T layout): psi_k = B[S] / N^{3/2} and psi = A^-1[S] / N^{3/2}, so psi_k
-// itself never has to be stored.  Both kinetic half-steps are then the same round trip through Fourier space,
-//   T -> pass B -> x D / N^{3/2} [-> aliased-mass partial] -> pass B^-1 -> T'
-// (first half: S -> scratch, simulation_object.rs:504-528; second half: kicked psi -> S, :552-581 with
-// check_alias :1249-1280), 16 B in and 16 B out per cell each.
-struct PsiBArgs {
-    const cplx* src;     // [.][n3] in the T layout, indexed by blockIdx.y
-    cplx* dst;           // [.][n3], indexed by blockIdx.y (T layout; k_psi_b_fwd: psi_k as [kx][ky][kz])
-    size_t n3;
-    const int* active;   // may be null
-    int s0;
-    const cplx* tw;
-    const cplx* drift;   // [n_streams][N]
-    const real* ksq;
-    real scale, alias_cut, fourpi2;
-    double* partial;     // [n_streams][ntiles]
-    int ntiles;
-};
-
-template <int ALIAS>
-__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_rt(PsiBArgs a) {
-    constexpr int N = tp::N;
-    __shared__ real plane[tp::B_PLANE];
-    __shared__ cplx tw[N];
-    __shared__ double red[ALIAS ? tp::B_THREADS / 64 : 1];
-    __shared__ cplx dl[N];                   // this stream's 1-D drift factors
-    __shared__ real kq[ALIAS ? N : 1];       // k_i^2 table
-    const int tid = threadIdx.x;
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (a.active != nullptr && !a.active[sg]) return;
-    // tables go to LDS up front: read from global memory in the middle of the kernel they would either expose an L2
-    // round trip behind the transform or be hoisted into sixteen live register pairs
-    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];
-    else if (tid < 2 * N) dl[tid - N] = a.drift[(size_t)sg * N + (tid - N)];
-    else if (ALIAS && tid < 3 * N) kq[tid - 2 * N] = a.ksq[tid - 2 * N];
-    lds_barrier();   // the z lines exchange inside their wavefront: no other barrier lies before the first table read
-    const RunB rb;
-    const RolesB r(plane);
-    const size_t trun = (size_t)ls * a.n3 + rb.off;
-    const unsigned toff = rb.toff;
-
-    cplx v[16];
-    b_forward(v, a.src, trun, toff, rb.tpi, r, tw, a.tw);
-    const int kx = rb.kx(r), ky = rb.ky(r);
-    {
-        const cplx dxy = cscale(cmul(dl[kx], dl[ky]), a.scale);
-        // four factors at a time: all sixteen table reads hoisted to the front would not fit the register budget
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[4 * c + i] = cmul(v[4 * c + i], cmul(dxy, dl[r.j0 + 16 * (4 * c + i)]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if constexpr (ALIAS) {
-        const real kxy = kq[kx] + kq[ky];
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const real k2 = (kxy + kq[r.j0 + 16 * q]) * a.fourpi2;
-            if (k2 > a.alias_cut) acc += (double)(v[q].x * v[q].x + v[q].y * v[q].y);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if ((tid & 63) == 0) red[tid >> 6] = acc;
-        lds_barrier();
-        if (tid == 0) {
-            double tot = red[0];
-#pragma unroll
-            for (int w = 1; w < tp::B_THREADS / 64; ++w) tot += red[w];
-            a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
-        }
-    }
-    b_inverse(v, a.dst, trun, toff, rb.tpi, r, tw, a.tw);
-}
-
-// psi_k = B[S] / N^{3/2} written as [kx][ky][kz] (kz contiguous, 256-byte rows): downloads of psi_k and the
-// synthesizer's psi_k products; k_transpose_xz turns it into the reference's element order.
-__global__ __launch_bounds__(tp::B_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_psi_b_fwd(PsiBArgs a) {
-    constexpr int N = tp::N;
-    __shared__ real plane[tp::B_PLANE];
-    __shared__ cplx tw[N];
-    const int tid = threadIdx.x;
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (a.active != nullptr && !a.active[sg]) return;
-    if (tid < N) tw[tid] = a.tw[TwLayout<N>::source(tid)];   // first read is behind the role-change barriers
-    const RunB rb;
-    const RolesB r(plane);
-    const int kx = rb.kx(r), ky = rb.ky(r);
-    cplx* __restrict__ prow = a.dst + (size_t)ls * a.n3 + ((size_t)kx * N + ky) * N + r.j0;
-    cplx v[16];
-    b_forward(v, a.src, (size_t)ls * a.n3 + rb.off, rb.toff, rb.tpi, r, tw, a.tw);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) prow[16 * q] = cscale(v[q], a.scale);
-}
-
-// Pass A of a plain psi transform: natural layout <-> T.
-//   SGN = -1: x lines forward, outer y stage, store T;   SGN = +1: the inverse, scaled, to the natural layout.
-template <int SGN>
-__global__ __launch_bounds__(tp::A_THREADS) void k_psi_a(PsiArgs a) {
-    constexpr int N = tp::N, E = 16, TPL = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (a.active != nullptr && !a.active[sg]) return;
-    const size_t so = (size_t)(a.src_local ? ls : sg) * a.n3, dof = (size_t)(a.dst_local ? ls : sg) * a.n3;
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-    cplx v[E];
-    if constexpr (SGN < 0) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = a.src[so + t.base + t.j0 + TPL * q];
-        LineFft<real, N, -1, true>::run(v, t.j0, t.line, tw);
-        a_store_T(v, t, lds, a.dst, dof);
-    } else {
-        a_load_T(v, t, lds, a.src, so);
-        LineFft<real, N, +1, true>::run(v, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) a.dst[dof + t.base + t.j0 + TPL * q] = cscale(v[q], a.scale);
-    }
-}
-
-// k_invx_rho with psi arriving in T (after pass B of the inverse transform): no drift factor left to apply.
-// The workgroup is alone on its CU (LDS), so it hides the load latency itself: stream b of a pair is
-// fetched while stream a is transformed, stream a of the next pair while W is.  The loop body is
-// straight-line code -- a finished stream is still transformed and its density dropped by a select,
-// the fetch past the end re-reads the last tile -- so that the number of loads in flight at every use
-// is a compile-time constant: the vector-memory counter retires in order, and a wait placed at a
-// branch merge has to assume the shorter path, i.e. drain everything.  For the same reason the stream
-// flags are read once into LDS: a flag load between a fetch and its use would wait for the fetch.
-template <int DENS>
-__global__ __launch_bounds__(tp::A_THREADS) void k_invx_rho3(PoisArgs a) {
-    constexpr int E = 16, TPL = 16, N = tp::N;
-    __shared__ cplx lds[tp::A_LDS];
-    __shared__ int act_lds[tp::MAX_BATCH + 2];
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    for (int i = threadIdx.x; i < tp::MAX_BATCH + 2; i += tp::A_THREADS) act_lds[i] = (i < a.nb) ? a.active[a.s0 + i] : 0;
-    a_load_twiddles(tw, a.tw);   // barrier inside
-
-    double dacc[DENS ? E : 1];
-    if constexpr (DENS) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) dacc[q] = 0.0;
-    }
-    const int pairs = (a.nb + 1) / 2, last = a.nb - 1;
-    cplx va[E], vb[E];
-    a_fetch_T(va, t, a.X, 0);
-    auto pair_body = [&](int p) {
-        const bool act_a = act_lds[2 * p] != 0, act_b = act_lds[2 * p + 1] != 0;   // uniform over the workgroup
-        a_fetch_T(vb, t, a.X, (size_t)min(2 * p + 1, last) * a.n3);
-        real rho0[E];
-        a_cols_to_lines(va, t, lds);
-        LineFft<real, N, +1, true>::run(va, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const cplx u = cscale(va[q], a.scale);
-            const real m2 = u.x * u.x + u.y * u.y;
-            rho0[q] = act_a ? a.mass_factor * m2 : (real)0;
-            if constexpr (DENS) dacc[q] += act_a ? (double)m2 : 0.0;
-        }
-        lds_barrier();   // line role -> column writes of the next exchange
-        a_cols_to_lines(vb, t, lds);
-        LineFft<real, N, +1, true>::run(vb, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const cplx u = cscale(vb[q], a.scale);
-            const real m2 = u.x * u.x + u.y * u.y;
-            vb[q] = mk<real>(rho0[q], act_b ? a.mass_factor * m2 : (real)0);
-            if constexpr (DENS) dacc[q] += act_b ? (double)m2 : 0.0;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        a_fetch_T(va, t, a.X, (size_t)min(2 * p + 2, last) * a.n3);
-        LineFft<real, N, -1, true>::run(vb, t.j0, t.line, tw);
-        a_store_T(vb, t, lds, a.W, (size_t)p * a.n3);   // a pair of finished streams stores zeros
-        lds_barrier();
-    };
-    // first pair peeled: the loop is then entered with the same loads and stores in flight as its back edge leaves
-    pair_body(0);
-    for (int p = 1; p < pairs; ++p) pair_body(p);
-    if constexpr (DENS) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) a.dens[t.base + t.j0 + TPL * q] += dacc[q];
-    }
-}
-
-// k_kick_fwdx with psi in T on both sides: phi_a + i phi_b and the half-drifted psi come back through
-// the outer y stage and the inverse x lines, the kicked psi leaves through forward x and the outer y stage.
-// Loads run ahead of their use (psi_a with W, psi_b from the middle of psi_a's turn); both streams of
-// the pair are always processed (see k_invx_rho3), only the store of a finished stream is skipped.
-__global__ __launch_bounds__(tp::A_THREADS) void k_kick3(PoisArgs a, const real* __restrict__ kick) {
-    constexpr int N = tp::N, E = 16;
-    __shared__ cplx lds[tp::A_LDS];
-    const int p = blockIdx.y;
-    const int sa = a.s0 + 2 * p;
-    const bool has_b = 2 * p + 1 < a.nb;
-    const int sb = has_b ? sa + 1 : sa;
-    const bool act_a = a.active[sa] != 0;
-    const bool act_b = has_b && a.active[sb] != 0;
-    if (!act_a && !act_b) return;
-    const real kca = kick[sa], kcb = kick[sb];
-    const size_t xa = (size_t)(2 * p) * a.n3, xb = (size_t)(has_b ? 2 * p + 1 : 2 * p) * a.n3;
-    const TileA t(blockIdx.x, threadIdx.x, lds);
-    cplx* tw = lds + 2 * tp::A_HALF;
-    a_load_twiddles(tw, a.tw);
-
-    cplx va[E], vb[E];
-    real phi[2][E];
-    {
-        cplx vw[E];
-        a_fetch_T(vw, t, a.W, (size_t)p * a.n3);
-        a_fetch_T(va, t, a.X, xa);
-        a_cols_to_lines(vw, t, lds);
-        LineFft<real, N, +1, true>::run(vw, t.j0, t.line, tw);
-#pragma unroll
-        for (int q = 0; q < E; ++q) { phi[0][q] = vw[q].x; phi[1][q] = vw[q].y; }
-        lds_barrier();
-    }
-    a_cols_to_lines(va, t, lds);
-    LineFft<real, N, +1, true>::run(va, t.j0, t.line, tw);
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        real sn, cs;
-        sincos_t(kca * phi[0][q], &sn, &cs);
-        va[q] = cmul(cscale(va[q], a.scale), mk<real>(cs, sn));
-    }
-    LineFft<real, N, -1, true>::run(va, t.j0, t.line, tw);
-    if (act_a) a_store_T(va, t, lds, a.Xout, xa);
-    lds_barrier();
-
-    a_fetch_T(vb, t, a.X, xb);
-    a_cols_to_lines(vb, t, lds);
-    LineFft<real, N, +1, true>::run(vb, t.j0, t.line, tw);
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        real sn, cs;
-        sincos_t(kcb * phi[1][q], &sn, &cs);
-        vb[q] = cmul(cscale(vb[q], a.scale), mk<real>(cs, sn));
-    }
-    LineFft<real, N, -1, true>::run(vb, t.j0, t.line, tw);
-    if (act_b) a_store_T(vb, t, lds, a.Xout, xb);
-}
-
-// dst[z][y][x] = src[x][y][z] for one N^3 grid (psi_k downloads from the P[kx][ky][kz] layout)
-__global__ __launch_bounds__(256) void k_transpose_xz(const cplx* __restrict__ src, cplx* __restrict__ dst, int N) {
-    __shared__ cplx tile[32][33];
-    const int y = blockIdx.z, x0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) tile[i][tx] = src[((size_t)(x0 + i) * N + y) * N + z0 + tx];
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) dst[((size_t)(z0 + i) * N + y) * N + x0 + tx] = tile[tx][i];
-}
-
-// Reduce the per-workgroup partials of one stream in a fixed order (bitwise reproducible).
-// MODE 0: sum -> alias_sum;  MODE 1: max (NaN wins) -> maxphi bits.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_reduce_partials(State st, const double* __restrict__ partial, int ntiles,
-                                                         int nvalid, int s0, const int* __restrict__ active) {
-    __shared__ double red[256];
-    const int s = s0 + blockIdx.x;
-    if (!active[s]) return;
-    const double* __restrict__ p = partial + (size_t)s * ntiles;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nvalid; i += 256) {   // nvalid <= ntiles: tiles the producing pass really has
-        const double v = p[i];
-        if (MODE == 0) acc += v;
-        else acc = (v != v) ? v : ((acc != acc) ? acc : (v > acc ? v : acc));
-    }
-    const double r = MODE == 0 ? block_sum<256>(acc, red) : block_max<256>(acc, red);
-    if (threadIdx.x == 0) {
-        if (MODE == 0) st.alias_sum[s] = r;
-        else st.maxphi[s] = (unsigned long long)__double_as_longlong(r);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// scalar kernels: one thread per stream, arithmetic order of the reference
-// ---------------------------------------------------------------------------
-// get_timestep (simulation_object.rs:878-934; expanding :939-990)
-__global__ void k_timestep(State st, Consts c, int s0, int nb) {
-#pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
-    const int s = s0 + i;
-    if (!st.active[s]) return;
-    const double pmax_d = __longlong_as_double((long long)st.maxphi[s]);
-    st.maxphi_step[s] = pmax_d;
-    const real pmax = (real)pmax_d;
-    const real two = (real)2.0, twopi = (real)(2.0 * 3.14159265358979323846);
-    real kinetic, potential, ttnd;
-    if (c.expanding) {
-        kinetic = c.cfl * two * c.box / sqrt(c.k2max);
-        potential = c.cfl * twopi / ((real)(2.0 * (double)st.a_now[s]) * pmax);
-        ttnd = st.tau_next[s];
-    } else {
-        kinetic = c.cfl * two * c.box / sqrt(c.k2max) / c.hbar;
-        potential = c.cfl * twopi * c.hbar / (two * pmax);
-        ttnd = (real)(st.dumps[s] + 1) * c.tfinal / (real)c.ndumps - st.time[s];
-    }
-    real dt = fmin(fmin(kinetic, potential), ttnd);
-    st.dt[s] = dt;
-    st.dump[s] = (dt == ttnd) ? 1 : 0;
-    if (!c.expanding) st.kick[s] = -dt / c.hbar;
-}
-
-// kinetic half-drift table exp(i c k_i^2 (2 pi)^2), c = -dt/4 * hbar_
-// (simulation_object.rs:504-516; expanding c = -dtau/4, :699-708).  The k-phase
-// is separable over the axes, so each pass multiplies by one 1-D factor.
-// Evaluated in double for both precisions.
-__global__ void k_drift_table(State st, Consts c, const real* __restrict__ ksq, int s0) {
-    const int s = s0 + blockIdx.y;
-    if (!st.active[s]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.N) return;
-    real coef;
-    {
-#pragma clang fp contract(off)
-        const real dt = st.dt[s];
-        coef = c.expanding ? (-dt / (real)4.0) : (-dt / (real)4.0 * c.hbar);
-    }
-    const real k2 = ksq[i] * c.fourpi2;
-    double sn, cs;
-    sincos((double)coef * (double)k2, &sn, &cs);
-    st.drift[(size_t)s * c.N + i] = mk<real>((real)cs, (real)sn);
-}
-
-// tail of update (simulation_object.rs:589-635; expanding :757-759,:814-844)
-__global__ void k_post_step(State st, Consts c, int s0, int nb, const real* new_time, const real* new_tau,
-                            const real* snapped_tau) {
-#pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
-    const int s = s0 + i;
-    if (!st.active[s]) return;
-    if (c.expanding) {
-        st.time[s] = new_time[s];
-        st.tau[s] = new_tau[s];
-    } else {
-        st.time[s] = st.time[s] + st.dt[s];
-    }
-    const real p_mass = (real)st.alias_sum[s] * c.dkpow;
-    const bool aliased = p_mass > c.alias_thr;
-    st.aliased[s] = aliased ? 1 : 0;
-    if (!aliased && st.dump[s]) {
-        st.dumps[s] += 1;
-        st.time[s] = (real)st.dumps[s] * c.tfinal / (real)c.ndumps;
-        if (c.expanding) st.tau[s] = snapped_tau[s];
-    }
-    st.nsteps[s] += 1;
-    st.active[s] = (!aliased && st.time[s] < c.tfinal) ? 1 : 0;
-}
-
-__global__ void k_publish(State st, Consts c, int ns, int fresh_max) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ns) return;
-    msm_stream_status o;
-    o.time = (double)st.time[s];
-    o.dt = (double)st.dt[s];
-    o.max_phi = fresh_max ? __longlong_as_double((long long)st.maxphi[s]) : st.maxphi_step[s];
-    o.alias_mass = (double)((real)st.alias_sum[s] * c.dkpow);
-    o.tau = (double)st.tau[s];
-    o.n_steps = st.nsteps[s];
-    o.current_dumps = st.dumps[s];
-    o.dump = st.dump[s];
-    o.active = st.active[s];
-    o.aliased = st.aliased[s];
-    st.status[s] = o;
-}
-
-// ---------------------------------------------------------------------------
-// initial-condition helpers
-// ---------------------------------------------------------------------------
-__global__ void k_interleave(cplx* __restrict__ dst, const real* __restrict__ re, const real* __restrict__ im, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = mk<real>(re[i], im[i]);
-}
-__global__ void k_split(const cplx* __restrict__ src, real* __restrict__ re, real* __restrict__ im, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const cplx v = src[i];
-        re[i] = v.x;
-        im[i] = v.y;
-    }
-}
-
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                                              unsigned k1, unsigned out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// Wigner / Husimi perturbation (sample_quantum_perturbation, ics.rs:560-646):
-// psi <- (psi sqrt(dV) + (N1 + i N2) / div) / sqrt(dV).  Element e draws its
-// pair from Philox4x32-10 counter (e_lo, e_hi, 0, 0), key = seed, Box-Muller in
-// double.  (ArrayFire's own normal stream is not reproducible from the
-// reference tree; statistics, not bits, are what carries over.)
-__global__ void k_sample(cplx* __restrict__ psi, size_t n, unsigned long long seed, real sqrt_dv, real div) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        unsigned r[4];
-        philox4x32_10((unsigned)(e & 0xffffffffu), (unsigned)(e >> 32), 0u, 0u, (unsigned)(seed & 0xffffffffu),
-                      (unsigned)(seed >> 32), r);
-        const unsigned long long b1 = (((unsigned long long)r[1] << 32) | r[0]) >> 11;
-        const unsigned long long b2 = (((unsigned long long)r[3] << 32) | r[2]) >> 11;
-        const double u1 = ((double)b1 + 0.5) * 0x1.0p-53, u2 = ((double)b2 + 0.5) * 0x1.0p-53;
-        const double rad = sqrt(-2.0 * log(u1));
-        double sn, cs;
-        sincos(2.0 * 3.14159265358979323846 * u2, &sn, &cs);
-        const cplx z = mk<real>((real)(rad * cs), (real)(rad * sn));
-        cplx v = psi[e];
-        v = mk<real>(v.x * sqrt_dv, v.y * sqrt_dv);
-        v = mk<real>(v.x + z.x / div, v.y + z.y / div);
-        psi[e] = mk<real>(v.x / sqrt_dv, v.y / sqrt_dv);
-    }
-}
-
-// Poisson resampling (sample_quantum_perturbation, ics.rs:495-558): count ~ Poisson(|psi|^2 dV n) per cell,
-// psi <- sqrt(count / n) e^{i arg psi} / sqrt(dV).  The reference draws from a thread-local host RNG
-// that cannot be reproduced; here element e draws from its own Philox4x32-10 stream, counter
-// (e_lo, e_hi, j, 1), key = seed: Knuth's product method below lambda = 10, Hoermann's PTRS
-// transformed rejection above.
-__device__ __forceinline__ void philox_u2(size_t e, unsigned j, unsigned lane, unsigned long long seed, double* u1, double* u2) {
-    unsigned r[4];
-    philox4x32_10((unsigned)(e & 0xffffffffu), (unsigned)(e >> 32), j, lane, (unsigned)(seed & 0xffffffffu),
-                  (unsigned)(seed >> 32), r);
-    const unsigned long long b1 = (((unsigned long long)r[1] << 32) | r[0]) >> 11;
-    const unsigned long long b2 = (((unsigned long long)r[3] << 32) | r[2]) >> 11;
-    *u1 = ((double)b1 + 0.5) * 0x1.0p-53;
-    *u2 = ((double)b2 + 0.5) * 0x1.0p-53;
-}
-__global__ void k_sample_poisson(cplx* __restrict__ psi, size_t n, unsigned long long seed, double dv, double npart) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const cplx v = psi[e];
-        const double m2 = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
-        const double lam = (m2 * dv) * npart;
-        double k = 0.0;
-        if (lam < 10.0) {
-            const double limit = exp(-lam);
-            double p = 1.0;
-            for (unsigned j = 0; j < 64; ++j) {
-                double u1, u2;
-                philox_u2(e, j, 1u, seed, &u1, &u2);
-                p *= u1;
-                if (!(p > limit)) break;
-                k += 1.0;
-                p *= u2;
-                if (!(p > limit)) break;
-                k += 1.0;
-            }
-        } else {
-            const double slam = sqrt(lam), loglam = log(lam);
-            const double b = 0.931 + 2.53 * slam;
-            const double a = -0.059 + 0.02483 * b;
-            const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-            const double vr = 0.9277 - 3.6224 / (b - 2.0);
-            for (unsigned j = 0; j < 64; ++j) {
-                double u1, V;
-                philox_u2(e, j, 1u, seed, &u1, &V);
-                const double U = u1 - 0.5, us = 0.5 - fabs(U);
-                k = floor((2.0 * a / us + b) * U + lam + 0.43);
-                if (us >= 0.07 && V <= vr) break;
-                if (k < 0.0 || (us < 0.013 && V > us)) { k = 0.0; continue; }
-                if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - lgamma(k + 1.0)) break;
-                k = 0.0;
-            }
-        }
-        const double amp = sqrt(k / npart) / sqrt(dv);
-        const double mag = sqrt(m2);
-        const double ux = mag > 0.0 ? (double)v.x / mag : 1.0, uy = mag > 0.0 ? (double)v.y / mag : 0.0;
-        psi[e] = mk<real>((real)(amp * ux), (real)(amp * uy));
-    }
-}
-
-// sum over streams of |psi_s|^2 (double accumulation)
-__global__ void k_density_sum(const cplx* __restrict__ X, size_t n3, int ns, double* __restrict__ out, int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (size_t)gridDim.x * blockDim.x) {
-        double acc = accumulate ? out[i] : 0.0;
-        for (int s = 0; s < ns; ++s) {
-            const cplx v = X[(size_t)s * n3 + i];
-            acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
-        }
-        out[i] = acc;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Pointwise operators of the unfused step: 1-D and 2-D grids (tiny next to the 3-D ones) and 3-D
-// grids whose edge is not a power of two up to 512 (chirp-z line transforms below).  Their step
-// is the reference's own sequence -- whole transforms (plain axis passes) with one kernel per
-// pointwise operator in between -- rather than the fused 3-D pipelines.
-// blockIdx.y = local stream; cell i = x + N y + N^2 z.
-// ---------------------------------------------------------------------------
-struct PwArgs {
-    const cplx* src;     // [.][n]
-    cplx* dst;
-    cplx* W;             // [batch][n] Poisson work grid, one stream per slot
-    real* PHI;
-    size_t n;
-    const int* active;
-    int s0, src_local, dst_local, N, dims;
-    const cplx* drift;
-    const real* ksq;
-    const real* kick;
-    real scale, mass_factor, pois_c, fourpi2, inv_n, alias_cut;
-    double* partial;     // [n_streams][ntiles]
-    int ntiles;
-};
-// cell i -> (x, y, z), x fastest; y and z are 0 on the axes a smaller grid does not have
-__device__ __forceinline__ void pw_xyz(const PwArgs& a, size_t i, int& x, int& y, int& z) {
-    const size_t r = i / a.N;
-    x = (int)(i - r * a.N);
-    z = (int)(r / a.N);
-    y = (int)(r - (size_t)z * a.N);
-}
-// spec_grid (utils/fft.rs:123-161): the axes are summed in order, then times (2 pi)^2
-__device__ __forceinline__ real pw_k2(const PwArgs& a, int x, int y, int z) {
-    real k2 = a.ksq[x];
-    if (a.dims >= 2) k2 = k2 + a.ksq[y];
-    if (a.dims >= 3) k2 = k2 + a.ksq[z];
-    return k2 * a.fourpi2;
-}
-// MODE 0: dst = src * D (kinetic half-step, simulation_object.rs:504-516)
-// MODE 1: dst = src * D * scale, plus this block's aliased-mass partial (:562-574, :1249-1280)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_pw_drift(PwArgs a) {
-    __shared__ double red[256];
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    const cplx* __restrict__ src = a.src + (size_t)(a.src_local ? ls : sg) * a.n;
-    cplx* __restrict__ dst = a.dst + (size_t)(a.dst_local ? ls : sg) * a.n;
-    const cplx* __restrict__ d = a.drift + (size_t)sg * a.N;
-    double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        int x, y, z;
-        pw_xyz(a, i, x, y, z);
-        cplx f = d[x];
-        if (a.dims >= 2) f = cmul(f, d[y]);
-        if (a.dims >= 3) f = cmul(f, d[z]);
-        cplx v = cmul(src[i], f);
-        if constexpr (MODE == 1) {
-            v = cscale(v, a.scale);
-            if (pw_k2(a, x, y, z) > a.alias_cut) acc += (double)(v.x * v.x + v.y * v.y);
-        }
-        dst[i] = v;
-    }
-    if constexpr (MODE == 1) {
-        const double tot = block_sum<256>(acc, red);
-        if (threadIdx.x == 0) a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
-    }
-}
-// W = M |psi * scale|^2 (calculate_density, :1031-1063); src = psi (scale 1) or the unscaled inverse transform
-__global__ __launch_bounds__(256) void k_pw_rho(PwArgs a) {
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    const cplx* __restrict__ src = a.src + (size_t)(a.src_local ? ls : sg) * a.n;
-    cplx* __restrict__ w = a.W + (size_t)ls * a.n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const cplx v = cscale(src[i], a.scale);
-        w[i] = mk<real>(a.mass_factor * (v.x * v.x + v.y * v.y), (real)0);
-    }
-}
-// W *= -C / k^2 / N^dims, k = 0 -> 0 (:1076-1102)
-__global__ __launch_bounds__(256) void k_pw_green(PwArgs a) {
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    cplx* __restrict__ w = a.W + (size_t)ls * a.n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        int x, y, z;
-        pw_xyz(a, i, x, y, z);
-        const real k2 = pw_k2(a, x, y, z);
-        const real g = (k2 == (real)0) ? (real)0 : (a.pois_c * recip_t(k2)) * a.inv_n;
-        w[i] = cscale(w[i], g);
-    }
-}
-// phi = Re W: per-block max|phi| (:905), optionally stored (msm_potential)
-template <int STOREPHI>
-__global__ __launch_bounds__(256) void k_pw_phi(PwArgs a) {
-    __shared__ double red[256];
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    const cplx* __restrict__ w = a.W + (size_t)ls * a.n;
-    real* __restrict__ phi = a.PHI + (size_t)ls * a.n;
-    double m = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const real p = w[i].x;
-        if constexpr (STOREPHI) phi[i] = p;
-        m = nanmax(fabs((double)p), m);
-    }
-    const double tot = block_max<256>(m, red);
-    if (threadIdx.x == 0) a.partial[(size_t)sg * a.ntiles + blockIdx.x] = tot;
-}
-// psi = (psi * scale) * exp(i kick Re W) (:535-545), in place on dst
-__global__ __launch_bounds__(256) void k_pw_kick(PwArgs a) {
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (!a.active[sg]) return;
-    cplx* __restrict__ x = a.dst + (size_t)ls * a.n;
-    const cplx* __restrict__ w = a.W + (size_t)ls * a.n;
-    const real kc = a.kick[sg];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        real sn, cs;
-        sincos_t(kc * w[i].x, &sn, &cs);
-        x[i] = cmul(cscale(x[i], a.scale), mk<real>(cs, sn));
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Line transform of ANY even length N <= 1024 (the reference only asks for an even edge,
-// utils/fft.rs:105; ArrayFire transforms any length): Bluestein's chirp-z algorithm,
-//   X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / N),
-// the convolution done with power-of-two transforms of length M >= 2N - 1 held in LDS:
-// decimation in frequency forward (natural in, bit-reversed out), times the precomputed
-// spectrum of conj(c) (stored bit-reversed, 1/M folded in), decimation in time back
-// (bit-reversed in, natural out).  A workgroup owns `lpw` neighbouring lines.  The inverse
-// transform is conj(F[conj(x)]).  Unnormalised; `scale` is applied on store.
-// ---------------------------------------------------------------------------
-struct AnyArgs {
-    const cplx* src;
-    cplx* dst;
-    size_t n3;
-    const int* active;   // may be null
-    int s0, src_local, dst_local;
-    int N, M, lpw;
-    size_t stride;       // N^axis: distance between consecutive points of a line
-    const cplx* chirp;   // [N]    exp(-i pi n^2 / N)
-    const cplx* bhat;    // [M]    F_M[conj chirp, wrapped] / M in bit-reversed order
-    const cplx* twm;     // [M/2]  exp(-2 pi i k / M)
-    real scale;
-};
-template <int SGN>
-__global__ __launch_bounds__(256) void k_line_any(AnyArgs a) {
-    extern __shared__ __align__(16) unsigned char any_smem[];
-    cplx* buf = reinterpret_cast<cplx*>(any_smem);            // [lpw][M]
-    const int ls = blockIdx.y, sg = a.s0 + ls;
-    if (a.active != nullptr && !a.active[sg]) return;
-    const cplx* __restrict__ src = a.src + (size_t)(a.src_local ? ls : sg) * a.n3;
-    cplx* __restrict__ dst = a.dst + (size_t)(a.dst_local ? ls : sg) * a.n3;
-    const int N = a.N, M = a.M, lpw = a.lpw, tid = threadIdx.x;
-    // line l = lo + stride * hi starts at hi * stride * N + lo; the lpw lines of a workgroup share hi
-    const size_t l0 = (size_t)blockIdx.x * lpw;
-    const size_t hi = l0 / a.stride, lo = l0 - hi * a.stride;
-    const size_t base = hi * a.stride * N + lo;
-    const bool xaxis = a.stride == 1;
-
-    for (int e = tid; e < lpw * M; e += 256) {
-        int ln, j;
-        if (xaxis) { ln = e / M; j = e - ln * M; } else { j = e / lpw; ln = e - j * lpw; }
-        cplx v = mk<real>(0, 0);
-        if (j < N) {
-            v = src[base + (xaxis ? (size_t)ln * N + j : (size_t)j * a.stride + ln)];
-            if (SGN > 0) v.y = -v.y;
-            v = cmul(v, a.chirp[j]);
-        }
-        buf[ln * M + j] = v;
-    }
-    __syncthreads();
-    const int halfM = M >> 1, nbf = lpw * halfM;
-    for (int half = halfM, tstep = 1; half >= 1; half >>= 1, tstep <<= 1) {
-        for (int b = tid; b < nbf; b += 256) {
-            const int ln = b / halfM, r = b - ln * halfM;
-            const int j = r & (half - 1), g = r / half;
-            const int i0 = ln * M + g * 2 * half + j, i1 = i0 + half;
-            const cplx u = buf[i0], v = buf[i1];
-            buf[i0] = cadd(u, v);
-            buf[i1] = cmul(csub(u, v), a.twm[j * tstep]);
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < lpw * M; e += 256) buf[e] = cmul(buf[e], a.bhat[e % M]);
-    __syncthreads();
-    for (int half = 1, tstep = halfM; half <= halfM; half <<= 1, tstep >>= 1) {
-        for (int b = tid; b < nbf; b += 256) {
-            const int ln = b / halfM, r = b - ln * halfM;
-            const int j = r & (half - 1), g = r / half;
-            const int i0 = ln * M + g * 2 * half + j, i1 = i0 + half;
-            cplx w = a.twm[j * tstep];
-            w.y = -w.y;
-            const cplx u = buf[i0], v = cmul(buf[i1], w);
-            buf[i0] = cadd(u, v);
-            buf[i1] = csub(u, v);
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < lpw * N; e += 256) {
-        int ln, j;
-        if (xaxis) { ln = e / N; j = e - ln * N; } else { j = e / lpw; ln = e - j * lpw; }
-        cplx v = cmul(buf[ln * M + j], a.chirp[j]);
-        if (SGN > 0) v.y = -v.y;
-        dst[base + (xaxis ? (size_t)ln * N + j : (size_t)j * a.stride + ln)] = cscale(v, a.scale);
-    }
-}
-
-// In-situ synthesizer sums (synthesizer/src/main.rs:63-93): acc = [psi | |psi|^2 | psik | |psik|^2], each n complex
-// doubles; psik arrives unitary and is scaled to the synthesizer's un-normalised transform.
-__global__ void k_synth_acc(const cplx* __restrict__ psi, const cplx* __restrict__ psik, double2* __restrict__ acc, size_t n,
-                            double kscale) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double pr = (double)psi[i].x, pi = (double)psi[i].y;
-        const double kr = (double)psik[i].x * kscale, ki = (double)psik[i].y * kscale;
-        double2 a = acc[i]; a.x += pr; a.y += pi; acc[i] = a;
-        double2 b = acc[n + i]; b.x += pr * pr + pi * pi; acc[n + i] = b;
-        double2 c = acc[2 * n + i]; c.x += kr; c.y += ki; acc[2 * n + i] = c;
-        double2 d = acc[3 * n + i]; d.x += kr * kr + ki * ki; acc[3 * n + i] = d;
-    }
-}
-// mean of one field to two real planes
-__global__ void k_synth_mean(const double2* __restrict__ f, double* __restrict__ re, double* __restrict__ im, size_t n, double inv) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double2 v = f[i];
-        re[i] = v.x * inv;
-        im[i] = v.y * inv;
-    }
-}
-// per-block partials of sum( <psi2> - |<psi>|^2 ), complex (main.rs:161-175)
-__global__ __launch_bounds__(256) void k_synth_qx(const double2* __restrict__ acc, size_t n, double inv, double2* __restrict__ partial) {
-    __shared__ double red[256];
-    double sr = 0.0, si = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double2 p = acc[i], p2 = acc[n + i];
-        const double mr = p.x * inv, mi = p.y * inv;
-        sr += p2.x * inv - (mr * mr + mi * mi);
-        si += p2.y * inv;
-    }
-    const double tr = block_sum<256>(sr, red);
-    __syncthreads();
-    const double ti = block_sum<256>(si, red);
-    if (threadIdx.x == 0) { partial[blockIdx.x].x = tr; partial[blockIdx.x].y = ti; }
-}
+#include "kernels_generic.inc"
+#include "kernels_two_pass.inc"
+#include "kernels_scalar.inc"
+#include "kernels_unfused.inc"
 
 // ---------------------------------------------------------------------------
 // size dispatch
