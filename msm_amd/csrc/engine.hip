@@ -410,6 +410,8 @@ class Engine final : public IEngine {
     // chirp-z line transforms: any even N that the power-of-two line engine does not serve
     bool anyn_ = false;
     int any_M_ = 0, any_lpw_ = 1;
+    std::vector<int> mix_radix_;   // non-empty: N is 2-3-5-smooth and takes the mixed-radix line transform instead
+    int mix_lpw_ = 1;
     cplx *chirp_ = nullptr, *bhat_ = nullptr, *twm_ = nullptr;
     template <int SGN> void launch_any(int ax, const PsiArgs& a, int nblk_y, int kind);
     bool two_pass_ = false;  // every 3-D transform in two passes (N = 256); P_ then holds S = pass A of psi between steps
@@ -624,7 +626,21 @@ int Engine::init(std::string& err) {
         tw[p].y = (real)sinl(ang);
     }
     HIP_TRY(hipMemcpy(tw_, tw.data(), sizeof(cplx) * N_, hipMemcpyHostToDevice));
-    if (anyn_) {
+    if (anyn_ && getenv("MSM_CHIRPZ") == nullptr) {
+        // 2-3-5-smooth edges: radix list of the mixed-radix line transform (radix 4 first, then 2, 3, 5)
+        int m = N_;
+        std::vector<int> rad;
+        while (m % 4 == 0) { rad.push_back(4); m /= 4; }
+        while (m % 2 == 0) { rad.push_back(2); m /= 2; }
+        while (m % 3 == 0) { rad.push_back(3); m /= 3; }
+        while (m % 5 == 0) { rad.push_back(5); m /= 5; }
+        if (m == 1 && rad.size() <= 12) {
+            mix_radix_ = rad;
+            mix_lpw_ = 1;
+            for (int c : {8, 4, 2}) if (N_ % c == 0 && (size_t)2 * c * N_ * sizeof(cplx) <= 65536) { mix_lpw_ = c; break; }
+        }
+    }
+    if (anyn_ && mix_radix_.empty()) {
         // chirp-z tables in extended precision: c[n] = exp(-i pi n^2 / N) with n^2 reduced mod 2N exactly,
         // the length-M spectrum of the wrapped conj(c) (bit-reversed, 1/M folded in), M-th roots of unity
         typedef std::complex<long double> lc;
@@ -702,6 +718,20 @@ void Engine::publish(bool fresh_max) {
 
 template <int SGN>
 void Engine::launch_any(int ax, const PsiArgs& p, int nblk_y, int kind) {
+    if (!mix_radix_.empty()) {
+        MixArgs m{};
+        m.src = p.src; m.dst = p.dst; m.n3 = p.n3; m.active = p.active; m.s0 = p.s0; m.src_local = p.src_local;
+        m.dst_local = p.dst_local; m.N = N_; m.tw = tw_; m.scale = p.scale; m.nst = (int)mix_radix_.size();
+        for (int i = 0; i < m.nst; ++i) m.radix[i] = mix_radix_[i];
+        m.stride = 1;
+        for (int i = 0; i < ax; ++i) m.stride *= (size_t)N_;
+        const size_t lines = n3_ / (size_t)N_;
+        m.lpw = (int)std::min<size_t>((size_t)mix_lpw_, lines);
+        const dim3 grid((unsigned)(lines / m.lpw), (unsigned)nblk_y);
+        const size_t lds = (size_t)2 * m.lpw * N_ * sizeof(cplx);
+        timed(kind, [&] { k_line_mixed<SGN><<<grid, dim3(256), lds, stream_>>>(m); });
+        return;
+    }
     AnyArgs a{};
     a.src = p.src; a.dst = p.dst; a.n3 = p.n3; a.active = p.active; a.s0 = p.s0; a.src_local = p.src_local;
     a.dst_local = p.dst_local; a.N = N_; a.M = any_M_; a.chirp = chirp_; a.bhat = bhat_; a.twm = twm_; a.scale = p.scale;

@@ -1,6 +1,6 @@
 """GPU: grids whose edge is not a power of two (any even N; the reference asserts only evenness,
 utils/fft.rs:105, and ArrayFire transforms any length) and N = 1024, against the numpy oracle.
-These sizes run chirp-z line transforms and the unfused step.  Tolerances as everywhere: 1e-11 * max|psi| after
+These sizes run mixed-radix or chirp-z line transforms and the unfused step.  Tolerances as everywhere: 1e-11 * max|psi| after
 10 steps (fp64), dt relative 1e-12; fp32 2e-4."""
 import numpy as np
 import pytest
@@ -24,8 +24,11 @@ def oracle_sim(dims, N, dtype=np.float64, psi=None, **over):
     return o.SimulationObject(list(o.simulation_iter(toml, dtype=dtype))[-1], psi=psi)
 
 
+# 2-3-5-smooth edges take the mixed-radix line transform, every other even edge (a factor 7, 11, 13 ... or a large prime)
+# the chirp-z one
 @pytest.mark.parametrize("dims,N", [(1, 6), (1, 10), (1, 100), (1, 750), (1, 1000), (1, 1024), (2, 6), (2, 12), (2, 96), (2, 600),
-                                    (3, 6), (3, 12), (3, 20), (3, 24), (3, 48), (3, 100)])
+                                    (3, 6), (3, 12), (3, 20), (3, 24), (3, 48), (3, 100),
+                                    (1, 14), (1, 154), (1, 998), (2, 28), (2, 202), (3, 14), (3, 22), (3, 98)])
 def test_fft_roundtrip_and_parseval(dims, N):
     rng = np.random.default_rng(dims * 10000 + N)
     psi = rng.standard_normal((N,) * dims) + 1j * rng.standard_normal((N,) * dims)
@@ -42,7 +45,10 @@ def test_fft_roundtrip_and_parseval(dims, N):
 @pytest.mark.parametrize("dims,N,precision,tol,dtol", [(3, 12, "f64", 1e-11, 1e-12), (3, 24, "f64", 1e-11, 1e-12),
                                                        (3, 40, "f64", 1e-11, 1e-12), (2, 48, "f64", 1e-11, 1e-12),
                                                        (1, 100, "f64", 1e-11, 1e-12), (1, 768, "f64", 1e-11, 1e-12),
-                                                       (3, 24, "f32", 2e-4, 2e-4), (2, 96, "f32", 2e-4, 2e-4)])
+                                                       (3, 24, "f32", 2e-4, 2e-4), (2, 96, "f32", 2e-4, 2e-4),
+                                                       (3, 14, "f64", 1e-11, 1e-12), (3, 26, "f64", 1e-11, 1e-12),
+                                                       (2, 44, "f64", 1e-11, 1e-12), (1, 182, "f64", 1e-11, 1e-12),
+                                                       (3, 28, "f32", 2e-4, 2e-4)])
 def test_steps_potential_and_alias_vs_oracle(dims, N, precision, tol, dtol):
     dtype = np.float64 if precision == "f64" else np.float32
     sim = oracle_sim(dims, N, dtype)
@@ -96,3 +102,24 @@ def test_wigner_streams_and_synth_3d_n20():
         for f in ("psi", "psi2", "psik", "psik2"):
             assert rel_err(ev.synth_fetch(0, f), want[f]) < 1e-11, f
         assert abs(ev.synth_qx(0) - want["Qx"]) < 1e-11
+
+
+def test_chirpz_and_mixed_radix_agree(monkeypatch):
+    """MSM_CHIRPZ=1 sends a 2-3-5-smooth edge through the chirp-z transform as well: both line transforms give the
+    same steps to rounding."""
+    N = 48
+    sim = oracle_sim(3, N)
+    out = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("MSM_CHIRPZ", "1")
+        with Evolver(size=N, n_streams=1, **TOPHAT) as ev:
+            ev.set_psi(0, sim.psi)
+            for _ in range(5):
+                ev.update()
+            out.append((ev.get_psi(0), ev.get_psik(0), ev.status()[0].dt))
+    assert rel_err(out[0][0], out[1][0]) < 1e-12 and rel_err(out[0][1], out[1][1]) < 1e-12
+    assert abs(out[0][2] / out[1][2] - 1) < 1e-13
+    for _ in range(5):
+        sim.update()
+    assert rel_err(out[1][0], sim.psi) < 1e-11
