@@ -461,6 +461,34 @@ def test_config5_shape_512_f32_expanding():
         assert st[0].n_steps == 2 and st[0].aliased == 0 and st[0].active == 1
 
 
+def test_config3_shape_256_64_streams():
+    """256^3 fp64, 64 Wigner streams in two sub-batches of 32 (the single-GPU benchmark configuration with stochastic
+    resampling on).  Size-independent properties: the step is unitary (norm of every checked stream stays 1), a
+    stream's trajectory does not depend on where it sits -- stream 63 repeats the seed of stream 0 from the other
+    sub-batch and the other lane of its Poisson pair -- and Parseval holds on the stored state."""
+    from msm_amd.ics import plane_wave_psi
+    N, ns = 256, 64
+    with Evolver(size=N, n_streams=ns, batch_streams=32, **PLANE) as ev:
+        ev.set_psi(0, plane_wave_psi(N))
+        for s in range(1, ns):
+            ev.copy_psi(s, 0)
+        for s in range(ns):
+            ev.sample(s, "Wigner", 1 if s == 63 else s + 1)
+        norm0 = {s: np.sum(np.abs(ev.get_psi(s)) ** 2) for s in (0, 5, 31, 32)}   # sim.py's ICs are not unit-normalised
+        for _ in range(3):
+            ev.update()
+        st = ev.status()
+        assert all(r.n_steps == 3 and r.active == 1 and r.aliased == 0 for r in st)
+        assert abs(st[63].dt / st[0].dt - 1) < 1e-12 and abs(st[63].time / st[0].time - 1) < 1e-12
+        assert abs(st[1].dt / st[0].dt - 1) > 1e-9                     # other seeds really are other trajectories
+        a, b = ev.get_psi(0), ev.get_psi(63)
+        assert rel_err(b, a) < 1e-12
+        for s, psi in ((0, a), (31, ev.get_psi(31)), (32, ev.get_psi(32))):
+            assert abs(np.sum(np.abs(psi) ** 2) / norm0[s] - 1) < 1e-12, s
+        assert rel_err(ev.get_psik(63), ev.get_psik(0)) < 1e-12
+        assert abs(np.sum(np.abs(ev.get_psik(5)) ** 2) / norm0[5] - 1) < 1e-12   # Parseval on the stored state
+
+
 def test_poisson_resampling(golden_dir):
     """Poisson scheme (ics.rs:495-558): counts from the stream's seeded Philox sequence.  Against the
     oracle's restatement of the same sampler (a count may differ where a rejection test lands within
