@@ -198,7 +198,7 @@ __device__ __forceinline__ void block_max2(double& a, double& b, double* red) {
     if constexpr (WAVES > 1) {
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
-        __syncthreads();
+        lds_barrier();   // LDS only: a look-ahead fetch of the caller stays in flight across the reduction
         a = red[0]; b = red[1];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { a = nanmax(a, red[2 * w]); b = nanmax(b, red[2 * w + 1]); }
