@@ -115,33 +115,42 @@ __device__ __forceinline__ void sincos_t(double x, double* s, double* c) {
 }
 __device__ __forceinline__ void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 
-template <int THREADS>
-__device__ __forceinline__ double block_sum(double v, double* red) {
+// Workgroup reductions in a fixed order (bitwise reproducible from run to run): whole wavefronts reduce by
+// lane exchange and meet in one LDS round, smaller workgroups walk an LDS tree.  The barriers order LDS traffic only,
+// so loads and stores the caller has in flight stay in flight.  `red` holds at least THREADS doubles.
+template <int THREADS, typename OP>
+__device__ __forceinline__ double block_reduce(double v, double* red, OP op) {
     const int tid = threadIdx.x;
-    red[tid] = v;
-    __syncthreads();
+    if constexpr (THREADS % 64 == 0) {
+        constexpr int WAVES = THREADS / 64;
 #pragma unroll
-    for (int off = THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off));
+        if constexpr (WAVES == 1) return v;
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        lds_barrier();
+        double r = red[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) r = op(r, red[w]);
+        return r;
+    } else {
+        red[tid] = v;
+        lds_barrier();
+#pragma unroll
+        for (int off = THREADS / 2; off > 0; off >>= 1) {
+            if (tid < off) red[tid] = op(red[tid], red[tid + off]);
+            lds_barrier();
+        }
+        return red[0];
     }
-    return red[0];
 }
 template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    return block_reduce<THREADS>(v, red, [](double a, double b) { return a + b; });
+}
+// NaN must win so that a poisoned potential is visible to the host
+template <int THREADS>
 __device__ __forceinline__ double block_max(double v, double* red) {
-    const int tid = threadIdx.x;
-    red[tid] = v;
-    __syncthreads();
-#pragma unroll
-    for (int off = THREADS / 2; off > 0; off >>= 1) {
-        // NaN must win so that a poisoned potential is visible to the host
-        if (tid < off) {
-            double a = red[tid], b = red[tid + off];
-            red[tid] = (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
-        }
-        __syncthreads();
-    }
-    return red[0];
+    return block_reduce<THREADS>(v, red, [](double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); });
 }
 
 // 1/x for the Green's function: hardware reciprocal plus one Newton step (about 1 ulp in double),
