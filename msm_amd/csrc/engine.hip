@@ -115,6 +115,19 @@ __device__ __forceinline__ void sincos_t(double x, double* s, double* c) {
 }
 __device__ __forceinline__ void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 
+// max with NaN winning, so that a poisoned potential stays visible
+__device__ __forceinline__ double nanmax(double a, double b) {
+    const double m = __builtin_fmax(a, b);
+    return __builtin_isunordered(a, b) ? __builtin_nan("") : m;   // one unordered compare and a select, no branches
+}
+// Branch-free accumulation of max|v| over many values: the running maximum ignores NaNs, a flag remembers them,
+// absmax_done puts the NaN back.  (A chain of nanmax compiles to nested exec-mask branches, two per value.)
+__device__ __forceinline__ void absmax_acc(double& m, bool& bad, double v) {
+    m = __builtin_fmax(m, __builtin_fabs(v));
+    bad |= (v != v);
+}
+__device__ __forceinline__ double absmax_done(double m, bool bad) { return bad ? __builtin_nan("") : m; }
+
 // Workgroup reductions in a fixed order (bitwise reproducible from run to run): whole wavefronts reduce by
 // lane exchange and meet in one LDS round, smaller workgroups walk an LDS tree.  The barriers order LDS traffic only,
 // so loads and stores the caller has in flight stay in flight.  `red` holds at least THREADS doubles.
@@ -150,7 +163,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // NaN must win so that a poisoned potential is visible to the host
 template <int THREADS>
 __device__ __forceinline__ double block_max(double v, double* red) {
-    return block_reduce<THREADS>(v, red, [](double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); });
+    return block_reduce<THREADS>(v, red, [](double a, double b) { return nanmax(a, b); });
 }
 
 // 1/x for the Green's function: hardware reciprocal plus one Newton step (about 1 ulp in double),
@@ -195,7 +208,6 @@ __device__ __forceinline__ void buf_st(float2 v, bufdesc r, unsigned lane_bytes,
 
 // max of two values per thread over the workgroup in one pass: wavefront shuffles, then one LDS
 // round over the (at most 16) wavefronts.  NaN wins so that a poisoned potential stays visible.
-__device__ __forceinline__ double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 template <int THREADS>
 __device__ __forceinline__ void block_max2(double& a, double& b, double* red) {
     constexpr int WAVES = (THREADS + 63) / 64;
