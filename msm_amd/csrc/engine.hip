@@ -267,6 +267,22 @@ struct Tile {
     }
 };
 
+// The same in two halves for kernels whose first tile loads can go out in between: the table entry's load is then the
+// oldest one in flight and its LDS write waits for it alone (loads retire in order), instead of the tile loads waiting
+// for the table.  One entry per thread: every pass workgroup has at least N threads.
+template <int N, int AX>
+__device__ __forceinline__ cplx tw_fetch(const cplx* __restrict__ tw_g) {
+    static_assert(!Geom<N, AX>::USES_LDS || Geom<N, AX>::THREADS >= N, "one table entry per thread");
+    if constexpr (Geom<N, AX>::USES_LDS) return tw_g[TwLayout<N>::source(threadIdx.x & (N - 1))];
+    else return mk<real>(0, 0);
+}
+template <int N, int AX>
+__device__ __forceinline__ void tw_publish(cplx* tw_lds, cplx v) {
+    if constexpr (Geom<N, AX>::USES_LDS) {
+        if ((int)threadIdx.x < N) tw_lds[threadIdx.x] = v;
+        if constexpr (AX == 0) lds_barrier();   // as in load_twiddles
+    }
+}
 template <int N, int AX>
 __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restrict__ tw_g) {
     using G = Geom<N, AX>;
