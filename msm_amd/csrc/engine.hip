@@ -557,6 +557,7 @@ int Engine::init(std::string& err) {
     if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
     if (N_ == tp::N && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
+    if (batch_ > GENERIC_MAX_BATCH) batch_ = GENERIC_MAX_BATCH;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
     const real L = (real)cfg_.axis_length;
