@@ -14,10 +14,20 @@ noise per stream seed, resident in HBM before the timed region starts.
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant pass kernel,
 timed with HIP events inside the timed region; `cpu_baseline` is the C/OpenMP
 port of the reference algorithm (oracle/sp_cpu.c) timed on this host on one stream.
+
+`roofline.achieved` is the kernel's own algorithmic bytes -- every input it must read once and every output it
+must write once, per stream-cell (KINDS*: second entry) -- over its measured launch time; `traffic` is what the
+PMC counters saw it move.  The whole-step figures `step_frac*` use the reference-level model of 224 B per update
+(7 transforms, one read and one write each); `model224_*` is that model's share attributed to the kernel.
+
+Without a launcher (`WORLD_SIZE` unset) `--gpus N` with N > 1 starts its own N rank processes, before anything
+in this process has touched a GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +44,9 @@ PLANE = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=64
              hbar_=0.01, ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+HBM_COPY_GBS = 6290.0          # best streaming copy measured on the part (achievable ceiling)
+B_MOVED_STEP_TWO_PASS = 192.0  # bytes the two-pass engine really moves per update (sum over its eight launches)
+B_MOVED_STEP_GENERIC = 368.0   # the three-pass engine
 B_ALG_STEP = 224.0             # algorithmic bytes per stream-cell update, fp64: 7 transforms x (16 B in + 16 B out)
 B_ALG_PASS = 32.0 / 3.0        # one axis pass is a third of a transform under the same model
 # pass kind -> (axis passes it performs per stream-cell, bytes it reads + writes per stream-cell)
@@ -103,6 +116,29 @@ def cpu_baseline(size, seconds_cap=30.0):
                 seconds=round(dt, 2))
 
 
+def self_launch(args):
+    """Start one fresh child process per rank (never a re-exec of a process that has used the GPU: this parent
+    has not touched one) and hand back the worst exit status; rank 0's JSON line passes through on stdout."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for r, pr in enumerate(procs):
+        code = pr.wait()
+        if code != 0:
+            print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
+            rc = rc or code
+            for other in procs:          # a dead rank leaves the others waiting in a collective: end them
+                if other.poll() is None:
+                    other.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,20 +150,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    force_dist = os.environ.get("MSM_BENCH_FORCE_DIST") == "1"   # rehearses the RCCL path on one GPU
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must equal --gpus")
     N = args.size
     n3 = N ** 3
 
     dist = torch = None
     hip_stream = None
-    use_dist = world > 1 or os.environ.get("MSM_BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on one GPU
+    use_dist = world > 1 or force_dist
     if use_dist:
         import torch            # before the first Evolver: libmsm_hip.so then binds to the HIP runtime torch loaded
         import torch.distributed as dist
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: this node shows {torch.cuda.device_count()} GPU(s), --gpus {args.gpus} needs "
+                             f"one per rank")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         hip_stream = torch.cuda.current_stream().cuda_stream or None
@@ -207,16 +249,26 @@ def main():
         npass, moved = (KINDS_TWO_PASS if two_pass else KINDS)[kind]
         cells_per_launch = n3 * min(args.batch, n_local)           # stream-cells one launch processes
         avg_s = kms / kcnt / 1e3
-        achieved = npass * B_ALG_PASS * cells_per_launch / avg_s / 1e9
+        # the kernel's own algorithmic bytes: each of its inputs read once, each of its outputs written once
+        achieved = moved * cells_per_launch / avg_s / 1e9
+        model224 = npass * B_ALG_PASS * cells_per_launch / avg_s / 1e9
+        traffic = measured_traffic(kind, two_pass, cells_per_launch, n3)             # PMC counters, or null
+        b_moved_step = B_MOVED_STEP_TWO_PASS if two_pass else B_MOVED_STEP_GENERIC
         roofline = dict(bound="hbm", kernel=kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=measured_traffic(kind, two_pass, cells_per_launch, n3),   # PMC counters, or null
-                        modelled_bytes_per_launch=moved * cells_per_launch,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        traffic_gbs=round(traffic / avg_s / 1e9, 1) if traffic else None,
+                        achievable_peak=HBM_COPY_GBS, achievable_frac=round(achieved / HBM_COPY_GBS, 4),
+                        alg_bytes_per_launch=moved * cells_per_launch,
                         avg_launch_ms=round(kms / kcnt, 4), launches=int(kcnt),
-                        alg_bytes_per_launch=npass * B_ALG_PASS * cells_per_launch,
-                        moved_gbs=round(moved * cells_per_launch / avg_s / 1e9, 1),
+                        # share of the reference-level 224-B model attributed to this kernel (not an HBM rate)
+                        model224_bytes_per_launch=npass * B_ALG_PASS * cells_per_launch,
+                        model224_gbs=round(model224, 1), model224_frac=round(model224 / HBM_PEAK_GBS, 4),
+                        # whole step: modelled (224 B per update: 7 transforms x 32 B) and really moved
                         step_alg_gbs=round(value * B_ALG_STEP / world / 1e9, 1),
                         step_frac=round(value * B_ALG_STEP / world / 1e9 / HBM_PEAK_GBS, 4),
+                        step_frac_is="modelled: 224 B per update / 8 TB/s",
+                        step_moved_gbs=round(value * b_moved_step / world / 1e9, 1),
+                        step_moved_frac=round(value * b_moved_step / world / 1e9 / HBM_PEAK_GBS, 4),
                         # stricter model: the four Poisson transforms counted as real-data transforms (168 B per update)
                         step_frac_real_poisson=round(value * 168.0 / world / 1e9 / HBM_PEAK_GBS, 4),
                         per_kind_ms={k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},

@@ -48,7 +48,7 @@ enum msm_direction { MSM_FORWARD = -1, MSM_INVERSE = 1 };
 typedef struct msm_config {
     int32_t struct_size;        /* = sizeof(msm_config), ABI check              */
     int32_t device;             /* HIP device ordinal (reference: set_device(0)) */
-    int32_t dims;               /* 3 (1 and 2 are not built yet)                 */
+    int32_t dims;               /* 1, 2 or 3 (utils/grid.rs:272-279)             */
     int32_t size;               /* N, even, in [2, 1024] (utils/fft.rs:105)      */
     int32_t precision;          /* msm_precision                                 */
     int32_t n_streams;          /* streams held by this context                  */
@@ -178,7 +178,8 @@ int32_t msm_set_clock(msm_ctx* ctx, int32_t stream, double time, double tau, int
 int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64);
 /* Fast path of the same product: register a DEVICE buffer of N^dims doubles (NULL to stop);
  * every following step zeroes it and leaves in it the sum of |psi_s(t + dt)|^2 over the
- * streams it advanced, accumulated inside the step's last pass at no extra HBM read. */
+ * streams that took the step (one that aliased in it is left out), accumulated inside the step's last pass at no extra HBM read (3-D
+ * power-of-two grids; the other grids add one read of the batch). */
 int32_t msm_step_density(msm_ctx* ctx, void* device_out_f64);
 
 /* In-situ synthesizer (synthesizer/src/main.rs:63-93,161-187; lib.rs:190-300): the per-dump

@@ -67,6 +67,7 @@ struct State {
     int* dump;
     int* dumps;
     int* aliased;
+    int* stepped;                   // took the step just finished and did not alias: mask of the step's tail
     long long* nsteps;
     cplx* drift;                    // [n_streams][N] exp(i c k_i^2 (2 pi)^2)
     msm_stream_status* status;      // [n_streams]
@@ -650,6 +651,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(dmalloc((void**)&st_.dump, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.dumps, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.aliased, sizeof(int) * ns_));
+    HIP_TRY(dmalloc((void**)&st_.stepped, sizeof(int) * ns_));
     HIP_TRY(dmalloc((void**)&st_.nsteps, sizeof(long long) * ns_));
     HIP_TRY(dmalloc((void**)&st_.drift, sizeof(cplx) * (size_t)ns_ * N_));
     HIP_TRY(dmalloc((void**)&st_.status, sizeof(msm_stream_status) * ns_));
@@ -740,6 +742,7 @@ int Engine::init(std::string& err) {
     HIP_TRY(hipMemcpy(st_.dump, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.dumps, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.aliased, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(st_.stepped, zi.data(), sizeof(int) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.nsteps, zl.data(), sizeof(long long) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.drift, one_c.data(), sizeof(cplx) * (size_t)ns_ * N_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(P_, 0, grid_bytes * ns_));
@@ -953,9 +956,12 @@ void Engine::lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, 
     k_pw_drift<1><<<grid, block, 0, stream_>>>(a);
     k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, pw_blocks_, s0, st_.active);
     k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
-    // potential of psi(t + dt) for the next timestep (:497)
-    fft3_plain(P_, false, X_, true, s0, nb, +1, st_.active);
-    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.active);
+    // potential of psi(t + dt) for the next timestep (:497); the tail also runs for a stream that has just reached
+    // the final time, so that its last density is part of msm_step_density's product
+    fft3_plain(P_, false, X_, true, s0, nb, +1, st_.stepped);
+    if (step_dens_)
+        k_density_add_active<<<(unsigned)std::min<size_t>((n3_ + 255) / 256, 2048), 256, 0, stream_>>>(X_, n3_, nb, st_.stepped, s0, step_dens_);
+    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.stepped);
 }
 
 // Before the first step P_ holds psi: size the first timestep from it (simulation_object.rs:497)
@@ -1008,12 +1014,15 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
             psi_rt(S, S, true, s0, nb, st_.active, PK_FWDZ_INVZ);
             k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::B_BLOCKS, s0, st_.active);
             k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
-            p.dens = step_dens_;               // potential of psi(t + dt) straight from the state
+            // potential of psi(t + dt) straight from the state, for every stream that took the step (one that has
+            // just reached the final time included: its last density belongs to msm_step_density's product)
+            p.dens = step_dens_;
+            p.active = st_.stepped;
             timed(PK_INVX_RHO, [&] {
                 if (step_dens_) k_invx_rho3<1><<<gridA, blockA, 0, stream_>>>(p);
                 else k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p);
             });
-            poisson_tail(s0, nb, false, true);
+            poisson_tail(s0, nb, false, true, true, st_.stepped);
         }
         return;
     }
@@ -1054,10 +1063,12 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
     });
     k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tiles_z_, s0, st_.active);
     k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
-    // streams that are still running: finish psi(t + dt) only as far as the next step needs it,
+    // streams that took the step: finish psi(t + dt) only as far as the next step needs it,
     // i.e. its density (and the ensemble density if asked for); psi itself is not written back
+    a.active = st_.stepped;
     launch_psi<+1, 0, 0>(1, a, nb, PK_INV_Y);
     p.dens = step_dens_;
+    p.active = st_.stepped;
     dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
@@ -1067,7 +1078,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
             else k_invx_rho<N, 0, 0, 0><<<grid, block, 0, stream_>>>(p);
         });
     });
-    poisson_tail(s0, nb, false, true);
+    poisson_tail(s0, nb, false, true, true, st_.stepped);
 }
 
 int Engine::step(std::string& err) {

@@ -66,8 +66,9 @@ def main(argv=None):
     if world > 1:
         import torch                    # before the Evolver: libmsm_hip.so binds to the HIP runtime torch loaded
         import torch.distributed as dist
-        ndev = max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank % ndev)
+        if args.backend == "nccl":      # gloo runs (CPU rehearsals of the driver) select no device
+            ndev = max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank % ndev)
         dist.init_process_group(args.backend)
     from .evolver import Evolver
 
@@ -159,36 +160,48 @@ def main(argv=None):
         on_dump(s, 0)                   # main.rs:61
     flush_synth()
     seen = [0] * n_local
+    alias_msg = None
     while True:
+        # One collective per step carries both flags: "some stream is still running" and "some stream aliased".
+        # Every rank therefore leaves the loop in the same iteration; a rank that raised on its own would leave
+        # the others blocked in the next all-reduce.
         active = False
         if ev is not None:
             st = ev.status()
             active = any(r.active for r in st)
-        go = active
+        go, abort = active, alias_msg is not None
         if dist is not None:
             import torch
-            flag = torch.tensor([1 if active else 0], dtype=torch.int32, device=coll_device())
+            flag = torch.tensor([1 if active else 0, 1 if alias_msg else 0], dtype=torch.int32, device=coll_device())
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            go = bool(flag.item())
-        if not go:
+            go, abort = bool(flag[0].item()), bool(flag[1].item())
+        if abort or not go:
             break
         if active:
             ev.update()
             st = ev.status()
             for s in range(n_local):
-                if st[s].aliased:
-                    raise SystemExit(f"simulation aliased: p_mass is {st[s].alias_mass} ({mine[s]['sim_name']})")
-                if st[s].dump and st[s].current_dumps > seen[s]:
+                if st[s].aliased and alias_msg is None:
+                    # the reference panics here (simulation_object.rs:607-617)
+                    alias_msg = (f"simulation aliased Fourier aliasing occurred; p_mass is {st[s].alias_mass} and the "
+                                 f"threshold was set at {t['alias_threshold']} with k2_cutoff = {t['k2_cutoff']} "
+                                 f"({mine[s]['sim_name']})")
+                if st[s].dump and st[s].current_dumps > seen[s] and not st[s].aliased:
                     seen[s] = st[s].current_dumps
                     on_dump(s, seen[s])
-        flush_synth()
-    if syn is not None:
+        flush_synth()       # entered by every rank, the aliased one included: its collectives stay matched
+    if syn is not None and not abort:
         syn.close()
     if ev is not None:
         ev.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if abort:
+        # every rank ends with the reference's non-zero panic status; the one that saw the aliasing says where
+        print(f"thread 'main' panicked at '{alias_msg}'" if alias_msg else
+              f"rank {rank}: stopping, a stream on another rank aliased", file=sys.stderr)
+        return 101
     return 0
 
 

@@ -149,3 +149,85 @@ def test_in_situ_synthesizer_two_ranks(tmp_path):
             assert np.allclose(re[..., 0] + 1j * im[..., 0], want[f], rtol=1e-12, atol=1e-12)
     qx = np.load(open(base / "Qx_real", "rb"))
     assert qx.shape == (2, 1, 1, 1) and np.allclose(qx[:, 0, 0, 0], want["Qx"].real, rtol=1e-12)
+
+
+class _FakeStatus:
+    def __init__(self):
+        self.active, self.aliased, self.dump, self.current_dumps, self.alias_mass, self.n_steps = 1, 0, 0, 0, 0.0, 0
+
+
+class _FakeStepper:
+    """Host stand-in for the Evolver in driver-logic tests: every update is a dump step; the stream sampled with
+    `alias_seed` reports aliasing in its second step (as a device context would, simulation_object.rs:607-617)."""
+    alias_seed = 2
+
+    def __init__(self, *, size, n_streams, dims=3, num_data_dumps=1, **_):
+        self.shape, self.n_streams, self.nd = (size,) * dims, n_streams, num_data_dumps
+        self.st = [_FakeStatus() for _ in range(n_streams)]
+        self.psi = [np.zeros(self.shape, complex) for _ in range(n_streams)]
+        self.seeds = [None] * n_streams
+
+    def derived(self):
+        return {"dx": 1.0}
+
+    def set_psi(self, s, psi):
+        self.psi[s] = np.array(psi)
+
+    def copy_psi(self, dst, src):
+        self.psi[dst] = self.psi[src].copy()
+
+    def sample(self, s, scheme, seed):
+        self.seeds[s] = seed
+
+    def update(self):
+        for s, r in enumerate(self.st):
+            if not r.active:
+                r.dump = 0
+                continue
+            r.n_steps += 1
+            if self.seeds[s] == self.alias_seed and r.n_steps == 2:
+                r.aliased, r.active, r.alias_mass, r.dump = 1, 0, 0.5, 0
+                continue
+            r.dump, r.current_dumps = 1, r.current_dumps + 1
+            r.active = 1 if r.current_dumps < self.nd else 0
+
+    def status(self):
+        return self.st
+
+    def get_psi(self, s):
+        return self.psi[s]
+
+    def close(self):
+        pass
+
+
+def _abort_worker(rank, world, port, toml, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import msm_amd.evolver
+    import msm_amd.run
+    msm_amd.evolver.Evolver = _FakeStepper
+    rc = msm_amd.run.main(["--toml", toml, "--backend", "gloo", "--out", out_dir])
+    with open(os.path.join(out_dir, f"rc{rank}"), "w") as f:
+        f.write(str(rc))
+
+
+@pytest.mark.timeout(180)
+def test_alias_on_one_rank_ends_every_rank(tmp_path):
+    """Two ranks, seeds 1 | 2 (+ the mean-field run on rank 0), six dumps: the stream on rank 1 aliases in its second
+    step.  Both ranks must leave the stepping loop in the same iteration and return the reference's panic status
+    instead of rank 0 running on into a collective that rank 1 never enters."""
+    import torch.multiprocessing as mp
+    toml = tmp_path / "run.toml"
+    toml.write_text('axis_length = 30.0\nfinal_sim_time = 40.0\ncfl = 0.5\nnum_data_dumps = 6\ntotal_mass = 1e11\n'
+                    'hbar_ = 0.05\nsim_name = "abort"\nk2_cutoff = 0.95\nalias_threshold = 0.02\ndims = 3\nsize = 8\n'
+                    '[ics]\ntype = "SphericalTophat"\nradius = 5.0\ndelta = 100.0\nslope = 50.0\n'
+                    '[sampling]\nscheme = "Wigner"\nseeds = "1, 2"\n')
+    mp.spawn(_abort_worker, args=(2, _free_port(), str(toml), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "rc0").read_text() == "101" and (tmp_path / "rc1").read_text() == "101"
+    # rank 0's streams wrote dumps 0..2 at most (the abort is seen one step after the aliasing), never all six
+    written = sorted(p.name for p in (tmp_path / "sim-data" / "abort-stream00001").iterdir())
+    assert "psi_00001_real" in written and "psi_00006_real" not in written
