@@ -73,11 +73,23 @@ def _norm_factor(dims: int, size: int) -> float:
     return 1.0 / float(size) ** (dims / 2.0)
 
 
+# Threads for the transforms of large grids (tests at 256^3 / 512^3 set it): > 1 switches from numpy's
+# pocketfft to scipy's, the same algorithm with a `workers` argument.  0 keeps numpy.
+FFT_WORKERS = 0
+
+
+def _fftn(a: np.ndarray, backward: bool) -> np.ndarray:
+    if FFT_WORKERS > 1:
+        import scipy.fft as sf
+        return sf.ifftn(a, norm="forward", workers=FFT_WORKERS) if backward else sf.fftn(a, workers=FFT_WORKERS)
+    return np.fft.ifftn(a, norm="forward") if backward else np.fft.fftn(a)
+
+
 def forward(a: np.ndarray) -> np.ndarray:
     """utils/fft.rs:6-31,60-78: unitary C2C FFT over all axes (scale applied
     after an unnormalised transform, forward sign e^{-2 pi i kn/N})."""
     dims, size = a.ndim, a.shape[0]
-    out = np.fft.fftn(a) * a.real.dtype.type(_norm_factor(dims, size))
+    out = _fftn(a, False) * a.real.dtype.type(_norm_factor(dims, size))
     return out.astype(a.dtype)
 
 
@@ -85,7 +97,7 @@ def inverse(a: np.ndarray) -> np.ndarray:
     """utils/fft.rs:33-58,80-98: unitary inverse (unnormalised backward
     transform times 1/N^{d/2})."""
     dims, size = a.ndim, a.shape[0]
-    out = np.fft.ifftn(a, norm="forward") * a.real.dtype.type(_norm_factor(dims, size))
+    out = _fftn(a, True) * a.real.dtype.type(_norm_factor(dims, size))
     return out.astype(a.dtype)
 
 

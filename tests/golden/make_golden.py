@@ -64,6 +64,33 @@ def run_dumps(toml, size, expanding, keep):
     return out
 
 
+def run_expanding(toml, size, dtype, nsteps=6, keep=(1, 2, 6)):
+    """Mean-field stream of an expanding box, step by step: beside the fields, the host-side scalars a caller of
+    msm_step_begin / msm_step_end supplies (scale factor, tau to the next dump, a1 + a2 of the half-kicks, new
+    time / tau, tau of the next dump time), so that the vectors drive the C ABI without the oracle."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import expanding_host as xh
+    params = list(o.simulation_iter(dict(toml, size=size), expanding=True, dtype=dtype))[-1]
+    sim = o.SimulationObject(params)
+    out = {"psi0": sim.psi.copy()}
+    scal, host = [], []
+    for i in range(1, nsteps + 1):
+        a_now, tau_next, snapped = xh.step_inputs(sim)
+        shadow = __import__("copy").deepcopy(sim)
+        dtau = float(shadow.update()["dt"])
+        a_sum, t_new, tau_new = xh.half_kicks(sim, dtau)
+        info = sim.update()
+        assert float(info["dt"]) == dtau
+        scal.append([float(info["dt"]), float(info["dump"]), float(info["alias_mass"]), float(info["max_phi"]),
+                     float(info["time"]), float(sim.parameters.tau)])
+        host.append([a_now, tau_next, snapped, a_sum, t_new, tau_new])
+        if i in keep:
+            out[f"psi_{i}"] = sim.psi.copy()
+    out["scalars"] = np.array(scal)
+    out["host"] = np.array(host)
+    return out
+
+
 if __name__ == "__main__":
     jobs = {
         "tophat_n8_f64": (TOPHAT, 8, -1, np.float64),
@@ -77,6 +104,10 @@ if __name__ == "__main__":
         "tophat_n32_f64": lambda: run(TOPHAT, 32, -1, np.float64, keep=(10,)),
         "tophat_n16_run200_f64": lambda: run_dumps(TOPHAT, 16, False, (0, 1, 200)),
         "tophat_cosmo_n16_run3_f64": lambda: run_dumps(COSMO, 16, True, (0, 1, 2, 3)),
+        # examples/spherical-tophat-cosmo.toml in single precision under the feature "expanding": the mode of the
+        # largest benchmark configuration (512^3 fp32), at a size the vectors stay small
+        "tophat_cosmo_n32_steps_f32": lambda: run_expanding(dict(COSMO, cfl=0.05), 32, np.float32),
+        "tophat_cosmo_n16_steps_f64": lambda: run_expanding(dict(COSMO, cfl=0.05), 16, np.float64),
     }
     for name, fn in extra.items():
         res = fn()

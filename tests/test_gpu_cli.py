@@ -302,3 +302,45 @@ def test_rank_world_partition(tmp_path):
         for k in range(6):
             assert rel(load_dump(two, n, k), load_dump(one, n, k)) < 1e-12, (n, k)   # pair partners differ: rounding only
     run_cli(two, cfg, "--rank", "2", "--world", "2", expect=2)
+
+
+def test_cold_gauss_ics_run(tmp_path):
+    # [ics] ColdGauss (ics.rs:24-162) with different mean/std per axis: mean[0]/std[0] belong to the fastest axis,
+    # i.e. the LAST axis of the dumped NPY (ics.rs:88-89,140-141); Husimi stream + mean-field run against the oracle
+    cfg = dict(TOPHAT, sim_name="cg", final_sim_time=0.4, num_data_dumps=2,
+               ics=dict(type="ColdGauss", mean=[10.0, 15.0, 21.0], std=[3.0, 5.0, 8.0]),
+               sampling=dict(seeds="2", scheme="Husimi"))
+    run_cli(tmp_path, cfg)
+    want0 = o.cold_gauss([10.0, 15.0, 21.0], [3.0, 5.0, 8.0], 30.0 / 16, 3, 16)
+    got0 = load_dump(tmp_path, "cg", 0)
+    assert rel(got0, want0) < 1e-13
+    # the narrowest Gaussian (std 3, mean 10) lies along the last axis of the dump
+    prof = [np.abs(got0).sum(axis=tuple(a for a in range(3) if a != ax)) for ax in range(3)]
+    widths = [float(np.sqrt(np.sum(p * (np.arange(16) - np.sum(p * np.arange(16)) / p.sum()) ** 2) / p.sum())) for p in prof]
+    assert widths[2] < widths[1] < widths[0]
+    sims = oracle_runs(cfg)
+    assert [s.parameters.sim_name for s in sims] == ["cg-stream00002", "cg"]
+    for sim in sims:
+        assert len(sim.dumps) == 3
+        for k, psi in sim.dumps:
+            assert rel(load_dump(tmp_path, sim.parameters.sim_name, k), psi) < 1e-11, (sim.parameters.sim_name, k)
+
+
+GAUSSIAN_MFT = dict(axis_length=30, final_sim_time=400, cfl=0.02, num_data_dumps=200, total_mass=1e10, hbar_=0.02,
+                    sim_name="gaussian-overdensity-512-mft", k2_cutoff=0.95, alias_threshold=0.02, dims=3, size=512,
+                    ics=dict(type="ColdGauss", mean=[15, 15, 15], std=[10, 10, 10]))
+
+
+def test_gaussian_overdensity_mft_example(tmp_path):
+    # examples/gaussian-overdensity-mft.toml (keys as shipped: integer-valued numbers, no [sampling] => the mean-field
+    # run alone) with `size` overridden to 64: --test builds the ICs and stops (main.rs:59); a shortened run then
+    # follows the oracle through its first dumps
+    cfg = dict(GAUSSIAN_MFT, size=64)
+    r = run_cli(tmp_path, cfg, "--test", "--verbose")
+    assert "Working on simulation gaussian-overdensity-512-mft" in r.stdout and not (tmp_path / "sim-data").exists()
+    short = dict(cfg, final_sim_time=4, num_data_dumps=2)       # same dump spacing as the shipped file (2 time units)
+    run_cli(tmp_path, short)
+    sims = oracle_runs(short)
+    assert len(sims) == 1 and len(sims[0].dumps) == 3 and sims[0].parameters.n_steps >= 3
+    for k, psi in sims[0].dumps:
+        assert rel(load_dump(tmp_path, "gaussian-overdensity-512-mft", k), psi) < 1e-11, k

@@ -220,3 +220,14 @@ def test_poisson_counts_distribution():
 def test_cold_gauss_kspace_norm():
     psi = o.cold_gauss_kspace([0.1, 0.0, -0.1], [0.2, 0.3, 0.25], 30 / 16, 3, 16, 7)
     assert abs(np.sum(np.abs(psi) ** 2) * (30 / 16) ** 3 - 1) < 1e-12
+
+
+def test_product_plane_wave_generator_equals_the_shipped_npz(golden_dir):
+    # msm_amd.ics.plane_wave_psi is what bench.py and the 256^3 tests start from: at the fixture's size it must be the
+    # reference's own initial_conditions/planeWave3d_e10_sym.npz (written by sim.py:185-186), bit for bit
+    from msm_amd.ics import plane_wave_psi
+    g = np.load(os.path.join(golden_dir, "planeWave3d_e10_sym.npz"))
+    psi = plane_wave_psi(16)
+    assert psi.shape == (16, 16, 16)
+    assert np.array_equal(psi.real, g["real"]) and np.array_equal(psi.imag, g["imag"])
+    assert np.array_equal(plane_wave_psi(8), o.plane_wave_ics(8))
