@@ -203,6 +203,16 @@ int32_t msm_synth_set_count(msm_ctx* ctx, int32_t slot, int64_t count);
 int32_t msm_synth_fetch(msm_ctx* ctx, int32_t slot, int32_t field, double* re, double* im);
 int32_t msm_synth_qx(msm_ctx* ctx, int32_t slot, double* qx_re, double* qx_im);
 int32_t msm_synth_release(msm_ctx* ctx, int32_t slot);
+/* msm_synth_qx for callers that cannot allocate (code under HIP graph capture, tight monitoring loops,
+ * harnesses that forbid hipMalloc); it has no counterpart in the reference.  Same value as msm_synth_qx,
+ * bit for bit, but nothing is allocated, freed, copied to the host or waited for: the reduction's partial
+ * sums live in a fixed 16-KiB workspace inside the library (one copy per GPU, held until the process ends),
+ * and {Re Qx, Im Qx} is written to `device_out2`, two doubles the GPU can address (device memory, or pinned
+ * host memory from msm_host_alloc), when the context's stream reaches the call (msm_sync to wait).
+ * Limit: grids of at most 2^30 cells (1024^3); larger ones are rejected with MSM_ERR_INVALID.
+ * The workspace is overwritten completely by every call, so nothing has to be cleared, but it is shared by
+ * every context on the same GPU: calls that overlap in time on one GPU (different streams) race. */
+int32_t msm_synth_qx_noalloc(msm_ctx* ctx, int32_t slot, double* device_out2);
 
 /* Timing helper for benchmarks: HIP events on the context's stream. */
 int32_t msm_timer_start(msm_ctx* ctx);

@@ -76,6 +76,7 @@ SYMBOLS = {
     "msm_synth_set_count": (C.c_int32, [_P, C.c_int32, C.c_int64]),
     "msm_synth_fetch": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P]),
     "msm_synth_qx": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "msm_synth_qx_noalloc": (C.c_int32, [_P, C.c_int32, _P]),
     "msm_synth_release": (C.c_int32, [_P, C.c_int32]),
     "msm_timer_start": (C.c_int32, [_P]),
     "msm_timer_stop_ms": (C.c_int32, [_P, C.POINTER(C.c_float)]),

@@ -239,6 +239,10 @@ int32_t msm_synth_qx(msm_ctx* ctx, int32_t slot, double* qx_re, double* qx_im) {
     MSM_CHECK_CTX(ctx);
     MSM_CALL(ctx, ctx->eng->synth_qx(slot, qx_re, qx_im, ctx->err));
 }
+int32_t msm_synth_qx_noalloc(msm_ctx* ctx, int32_t slot, double* device_out2) {
+    MSM_CHECK_CTX(ctx);
+    MSM_CALL(ctx, ctx->eng->synth_qx_noalloc(slot, device_out2, ctx->err));
+}
 int32_t msm_synth_release(msm_ctx* ctx, int32_t slot) {
     MSM_CHECK_CTX(ctx);
     MSM_CALL(ctx, ctx->eng->synth_release(slot, ctx->err));

@@ -24,6 +24,7 @@
 #include <complex>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -301,6 +302,41 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
 #include "kernels_unfused.inc"
 
 // ---------------------------------------------------------------------------
+// Fixed workspace of the entry point that allocates nothing (msm_synth_qx_noalloc): the per-workgroup partial sums
+// of the Qx reduction.  Every GPU this library runs on holds its own copy of the array until the process ends
+// (16 KiB per precision).  Host code never uses the array's name as an address: qx_scratch_of() asks the runtime
+// for the copy's device address, once per device with that device current, and everything else uses that pointer.
+// ---------------------------------------------------------------------------
+constexpr int QX_PARTS = 1024;                       // workgroups of k_synth_qx = partial sums
+constexpr size_t QX_MAX_CELLS = (size_t)1 << 30;     // 1024^3, the largest grid the library builds
+static __device__ __align__(256) double2 scratch[QX_PARTS];
+
+constexpr int QX_MAX_DEVICES = 64;
+double2* g_qx_scratch[QX_MAX_DEVICES] = {};
+std::mutex g_qx_mutex;
+// device address of `scratch` on the CURRENT device `dev`; null + err on failure
+double2* qx_scratch_of(int dev, std::string& err) {
+    if (dev < 0 || dev >= QX_MAX_DEVICES) { err = "device ordinal beyond the scratch table"; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_qx_mutex);
+    if (!g_qx_scratch[dev]) {
+        double2* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) { err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return nullptr; }
+        g_qx_scratch[dev] = ptr;
+    }
+    return g_qx_scratch[dev];
+}
+// sums the partials in index order (the order msm_synth_qx's host loop uses) and scales by dv
+__global__ void k_qx_finish(const double2* __restrict__ part, int n, double dv, double* __restrict__ out2) {
+#pragma clang fp contract(off)
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double sr = 0.0, si = 0.0;
+    for (int i = 0; i < n; ++i) { sr += part[i].x; si += part[i].y; }
+    out2[0] = sr * dv;
+    out2[1] = si * dv;
+}
+
+// ---------------------------------------------------------------------------
 // size dispatch
 // ---------------------------------------------------------------------------
 template <typename F>
@@ -364,6 +400,7 @@ class Engine final : public IEngine {
     int synth_set_count(int slot, long long count, std::string& err) override;
     int synth_fetch(int slot, int field, double* re, double* im, std::string& err) override;
     int synth_qx(int slot, double* re, double* im, std::string& err) override;
+    int synth_qx_noalloc(int slot, double* out2, std::string& err) override;
     int synth_release(int slot, std::string& err) override;
     int timer_start(std::string& err) override;
     int timer_stop(float* ms, std::string& err) override;
@@ -471,6 +508,7 @@ class Engine final : public IEngine {
     int dl_next_ = 0;
     struct SynthSlot { double2* sums = nullptr; long long count = 0; };
     std::vector<SynthSlot> synth_;
+    double2* qx_scratch_ = nullptr;   // this device's copy of `scratch`
     int synth_check(int slot, std::string& err) const {
         if (slot < 0 || slot >= (int)synth_.size() || !synth_[slot].sums) { err = "synthesizer slot is not open"; return MSM_ERR_INVALID; }
         return MSM_OK;
@@ -552,6 +590,8 @@ int Engine::init(std::string& err) {
     }
     HIP_TRY(hipEventCreate(&ev0_));
     HIP_TRY(hipEventCreate(&ev1_));
+    qx_scratch_ = qx_scratch_of(cfg_.device, err);   // cfg_.device is current here
+    if (!qx_scratch_) return MSM_ERR_HIP;
 
     // sub-batch: bounded scratch (X + W + PHI = 2 complex grids per stream), whole Poisson pairs
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
@@ -1513,6 +1553,20 @@ int Engine::synth_qx(int slot, double* re, double* im, std::string& err) {
     const double dv = std::pow((double)dx_, (double)dims_);
     *re = sr * dv;
     *im = si * dv;
+    return MSM_OK;
+}
+
+// The same product without any allocation, synchronisation or host copy: partials go to this device's fixed
+// workspace, a one-thread kernel adds them in the order synth_qx's host loop does, the result lands in the
+// caller's device-accessible buffer when the context's stream gets there.
+int Engine::synth_qx_noalloc(int slot, double* out2, std::string& err) {
+    if (int rc = synth_check(slot, err)) return rc;
+    if (!out2) { err = "null output"; return MSM_ERR_INVALID; }
+    if (synth_[slot].count < 1) { err = "nothing accumulated"; return MSM_ERR_STATE; }
+    if (n3_ > QX_MAX_CELLS) { err = "grid exceeds the fixed workspace's limit of 2^30 cells"; return MSM_ERR_INVALID; }
+    k_synth_qx<<<QX_PARTS, 256, 0, stream_>>>(synth_[slot].sums, n3_, 1.0 / (double)synth_[slot].count, qx_scratch_);
+    k_qx_finish<<<1, 64, 0, stream_>>>(qx_scratch_, QX_PARTS, std::pow((double)dx_, (double)dims_), out2);
+    HIP_TRY(hipGetLastError());
     return MSM_OK;
 }
 

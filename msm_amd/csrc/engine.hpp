@@ -33,6 +33,7 @@ struct IEngine {
     virtual int synth_set_count(int slot, long long count, std::string& err) = 0;
     virtual int synth_fetch(int slot, int field, double* re, double* im, std::string& err) = 0;
     virtual int synth_qx(int slot, double* re, double* im, std::string& err) = 0;
+    virtual int synth_qx_noalloc(int slot, double* out2, std::string& err) = 0;
     virtual int synth_release(int slot, std::string& err) = 0;
     virtual int timer_start(std::string& err) = 0;
     virtual int timer_stop(float* ms, std::string& err) = 0;

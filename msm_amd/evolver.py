@@ -234,6 +234,10 @@ class Evolver:
         self._check(self._lib.msm_synth_qx(self._ctx, slot, C.byref(re), C.byref(im)), "msm_synth_qx")
         return complex(re.value, im.value)
 
+    def synth_qx_noalloc(self, slot: int, device_out2: int):
+        """Qx into two doubles at a GPU-addressable address; asynchronous, allocates nothing."""
+        self._check(self._lib.msm_synth_qx_noalloc(self._ctx, slot, device_out2), "msm_synth_qx_noalloc")
+
     def synth_release(self, slot: int):
         self._check(self._lib.msm_synth_release(self._ctx, slot), "msm_synth_release")
 
