@@ -7,7 +7,8 @@
 A "step" is one SimulationObject::update of every stream.  The 256 streams are
 block-partitioned over the N ranks (one process per GPU, no data-path exchange
 between streams); with N > 1 every step also sums |psi|^2 over the local
-streams and all-reduces that mean-density grid over RCCL.  Inputs are synthetic:
+streams and all-reduces that mean-density grid over RCCL inside the library
+(msm_mean_density_begin), overlapped with the next step.  Inputs are synthetic:
 the reference's plane-wave ICs (sim.py) regenerated at N = 256 plus Wigner
 noise per stream seed, resident in HBM before the timed region starts.
 
@@ -38,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 import msm_amd  # noqa: E402
 from msm_amd.ics import plane_wave_psi  # noqa: E402
-from msm_amd.sharding import allreduce_density, partition_streams  # noqa: E402
+from msm_amd.sharding import partition_streams  # noqa: E402
 
 PLANE = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=64, total_mass=3e16,
              hbar_=0.01, ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)
@@ -162,25 +163,28 @@ def main():
     n3 = N ** 3
 
     dist = torch = None
-    hip_stream = None
     use_dist = world > 1 or force_dist
     if use_dist:
+        # torch.distributed (gloo, CPU) is the launcher-side plumbing: it hands the communicator id around and agrees on
+        # the clock.  The density grids themselves go through the library's own RCCL communicator (msm_comm_init).
         import torch            # before the first Evolver: libmsm_hip.so then binds to the HIP runtime torch loaded
         import torch.distributed as dist
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: this node shows {torch.cuda.device_count()} GPU(s), --gpus {args.gpus} needs "
                              f"one per rank")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        hip_stream = torch.cuda.current_stream().cuda_stream or None
+        dist.init_process_group("gloo")
 
     # block partition of the seed list 1..streams (simulator/src/utils/io.rs:183-213 order)
     per = (args.streams + world - 1) // world
     first, n_local = partition_streams(args.streams, world, rank)
     seeds = [first + 1 + i for i in range(n_local)]
 
-    ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank,
-                         hip_stream=hip_stream, **PLANE)
+    ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank, **PLANE)
+    if use_dist:
+        box = [msm_amd.Evolver.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ev.comm_init(box[0], rank, world)                       # RCCL over xGMI, one rank per GPU
+        ev.mean_density_begin(args.streams)                     # every step now all-reduces sum_s |psi_s|^2
     psi0 = plane_wave_psi(N)
     ev.set_psi(0, psi0)
     for s in range(1, n_local):
@@ -189,27 +193,18 @@ def main():
         ev.sample(s, "Wigner", seed)       # stochastic stream resampling, one seed per stream
     del psi0
 
-    dens = work = None
-    if use_dist:
-        dens = [torch.empty(n3, dtype=torch.float64, device="cuda") for _ in range(2)]
-        work = [None, None]
+    taken = [0]
 
     def one_step(i):
-        if use_dist:
-            b = i & 1
-            if work[b] is not None:
-                work[b].wait()                                  # the all-reduce of two steps ago ...
-                torch.cuda.current_stream().synchronize()       # ... has really finished before its buffer is reused
-            ev.step_density(dens[b].data_ptr())                 # the step leaves sum_s |psi_s|^2 here
-        ev.update()
-        ev.sync()                                               # per-step status (dt, dump flags) on the host; the
-        if use_dist:                                            # density is complete before the collective may read it
-            work[b] = allreduce_density(dist, dens[b], async_op=True)   # overlaps the next step; mean = / streams
+        taken[0] += 1
+        ev.update()     # with a communicator: the step's density sum is all-reduced on a second stream, beside step i + 1
+        ev.sync()       # per-step status (dt, dump flags) on the host
 
     def barrier():
         ev.sync()
         if use_dist:
-            torch.cuda.synchronize()
+            if taken[0]:
+                ev.mean_density(to_host=False)                  # the last step's all-reduce has finished
             dist.barrier()
 
     for i in range(args.warmup):
@@ -220,10 +215,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
-    if use_dist:
-        for w in work:
-            if w is not None:
-                w.wait()
     barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = ev.timer_stop_ms()
@@ -234,7 +225,7 @@ def main():
     aliased = sum(s.aliased for s in st)
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

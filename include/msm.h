@@ -214,6 +214,35 @@ int32_t msm_synth_release(msm_ctx* ctx, int32_t slot);
  * every context on the same GPU: calls that overlap in time on one GPU (different streams) race. */
 int32_t msm_synth_qx_noalloc(msm_ctx* ctx, int32_t slot, double* device_out2);
 
+/* Several GPUs: one process and one context per GPU, the seed streams partitioned by the caller
+ * (they are independent simulations, simulator/src/main.rs:43-79, so no exchange is needed to evolve
+ * them).  What crosses GPUs are the ensemble products the reference's post-processor builds from the
+ * dumps (synthesizer/src/lib.rs:217-229,285-306; its own MPI gathers: lib.rs:466-583): here they are
+ * summed in situ by RCCL all-reduces over xGMI.  librccl is bound at run time on the first call.
+ * msm_comm_unique_id: 128 bytes (an ncclUniqueId) that one rank creates and hands to all others by any
+ *   means (file, environment, a launcher's key-value store).
+ * msm_comm_init: joins the communicator; collective, every rank passes the same id and world.
+ * msm_comm_allreduce_f64: n <= 64 host doubles reduced over the ranks in place (op 0 sum, 2 max, 3 min;
+ *   RCCL's codes), synchronous -- the flags and clocks a multi-rank driver agrees on.
+ * msm_mean_density_begin: from now on every step (msm_step / msm_step_end) also leaves
+ *   sum over ALL ranks' streams of |psi_s(t + dt)|^2: the local sum is formed inside the step's last
+ *   pass, its all-reduce is enqueued on a second stream behind an event and overlaps the next step
+ *   (two buffers alternate).  Collective: every rank must then take the same number of steps.
+ *   The product never feeds back into any stream's potential.  total_streams = the divisor of the mean.
+ * msm_mean_density: waits for the all-reduce of the most recent step and returns the mean density
+ *   <|psi|^2> as N^dims doubles: copied to `host_or_null` if given, and/or as a device pointer that stays
+ *   valid until the next call.
+ * msm_synth_allreduce: sums slot `slot` of the in-situ synthesizer (fields and stream count) over the
+ *   ranks; collective, a rank that has accumulated nothing contributes zeros.  Afterwards
+ *   msm_synth_fetch / msm_synth_qx on any rank return the ensemble's products. */
+#define MSM_COMM_ID_BYTES 128
+int32_t msm_comm_unique_id(void* id_out);
+int32_t msm_comm_init(msm_ctx* ctx, const void* id, int32_t rank, int32_t world);
+int32_t msm_comm_allreduce_f64(msm_ctx* ctx, double* values, int32_t n, int32_t op);
+int32_t msm_mean_density_begin(msm_ctx* ctx, int64_t total_streams);
+int32_t msm_mean_density(msm_ctx* ctx, double* host_or_null, void** device_or_null);
+int32_t msm_synth_allreduce(msm_ctx* ctx, int32_t slot);
+
 /* Timing helper for benchmarks: HIP events on the context's stream. */
 int32_t msm_timer_start(msm_ctx* ctx);
 int32_t msm_timer_stop_ms(msm_ctx* ctx, float* ms);

@@ -78,6 +78,12 @@ SYMBOLS = {
     "msm_synth_qx": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msm_synth_qx_noalloc": (C.c_int32, [_P, C.c_int32, _P]),
     "msm_synth_release": (C.c_int32, [_P, C.c_int32]),
+    "msm_comm_unique_id": (C.c_int32, [_P]),
+    "msm_comm_init": (C.c_int32, [_P, _P, C.c_int32, C.c_int32]),
+    "msm_comm_allreduce_f64": (C.c_int32, [_P, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
+    "msm_mean_density_begin": (C.c_int32, [_P, C.c_int64]),
+    "msm_mean_density": (C.c_int32, [_P, _P, C.POINTER(_P)]),
+    "msm_synth_allreduce": (C.c_int32, [_P, C.c_int32]),
     "msm_timer_start": (C.c_int32, [_P]),
     "msm_timer_stop_ms": (C.c_int32, [_P, C.POINTER(C.c_float)]),
     "msm_profile": (C.c_int32, [_P, C.c_int32]),

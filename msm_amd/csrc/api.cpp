@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "comm.hpp"
 #include "engine.hpp"
 
 struct msm_ctx {
@@ -247,6 +248,42 @@ int32_t msm_synth_release(msm_ctx* ctx, int32_t slot) {
     MSM_CHECK_CTX(ctx);
     MSM_CALL(ctx, ctx->eng->synth_release(slot, ctx->err));
 }
+int32_t msm_comm_unique_id(void* id_out) {
+    try {
+        if (!id_out) return MSM_ERR_INVALID;
+        std::string err;
+        const msm::Rccl* r = msm::rccl(err);
+        if (!r) { g_create_error = err; return MSM_ERR_INVALID; }
+        msm::CommId id;
+        const int rc = r->get_unique_id(&id);
+        if (rc != 0) { g_create_error = std::string("ncclGetUniqueId: ") + r->error_string(rc); return MSM_ERR_HIP; }
+        std::memcpy(id_out, id.bytes, msm::COMM_ID_BYTES);
+        return MSM_OK;
+    } catch (...) {
+        return MSM_ERR_INVALID;
+    }
+}
+int32_t msm_comm_init(msm_ctx* ctx, const void* id, int32_t rank, int32_t world) {
+    MSM_CHECK_CTX(ctx);
+    MSM_CALL(ctx, ctx->eng->comm_init(id, rank, world, ctx->err));
+}
+int32_t msm_comm_allreduce_f64(msm_ctx* ctx, double* values, int32_t n, int32_t op) {
+    MSM_CHECK_CTX(ctx);
+    MSM_CALL(ctx, ctx->eng->comm_allreduce_f64(values, n, op, ctx->err));
+}
+int32_t msm_mean_density_begin(msm_ctx* ctx, int64_t total_streams) {
+    MSM_CHECK_CTX(ctx);
+    MSM_CALL(ctx, ctx->eng->mean_density_begin(total_streams, ctx->err));
+}
+int32_t msm_mean_density(msm_ctx* ctx, double* host_or_null, void** device_or_null) {
+    MSM_CHECK_CTX(ctx);
+    MSM_CALL(ctx, ctx->eng->mean_density(host_or_null, device_or_null, ctx->err));
+}
+int32_t msm_synth_allreduce(msm_ctx* ctx, int32_t slot) {
+    MSM_CHECK_CTX(ctx);
+    MSM_CALL(ctx, ctx->eng->synth_allreduce(slot, ctx->err));
+}
+
 int32_t msm_timer_start(msm_ctx* ctx) {
     MSM_CHECK_CTX(ctx);
     MSM_CALL(ctx, ctx->eng->timer_start(ctx->err));

@@ -29,6 +29,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "comm.hpp"
 #include "engine.hpp"
 #include "fft_core.hpp"
 
@@ -402,6 +403,11 @@ class Engine final : public IEngine {
     int synth_qx(int slot, double* re, double* im, std::string& err) override;
     int synth_qx_noalloc(int slot, double* out2, std::string& err) override;
     int synth_release(int slot, std::string& err) override;
+    int comm_init(const void* id, int rank, int world, std::string& err) override;
+    int mean_density_begin(long long total_streams, std::string& err) override;
+    int mean_density(double* host, void** dev, std::string& err) override;
+    int synth_allreduce(int slot, std::string& err) override;
+    int comm_allreduce_f64(double* vals, int n, int op, std::string& err) override;
     int timer_start(std::string& err) override;
     int timer_stop(float* ms, std::string& err) override;
     int profile(int enable, std::string& err) override;
@@ -516,6 +522,28 @@ class Engine final : public IEngine {
     // psi (natural order) and unitary psi_k (reference order) of stream s on the device; valid until the next call
     void materialise(int s, const cplx** psi, const cplx** psik);
 
+    // ---- several GPUs: one context per process and GPU, RCCL between them (bound at run time, comm.hpp)
+    const Rccl* rccl_ = nullptr;
+    void* comm_ = nullptr;
+    int comm_rank_ = 0, comm_world_ = 1;
+    hipStream_t comm_stream_ = nullptr;                 // collectives of the per-step density run beside the next step
+    static constexpr int COMM_SMALL = 64;
+    double *comm_small_d_ = nullptr, *comm_small_h_ = nullptr;
+    // per-step ensemble density: two sum buffers used alternately, so that the all-reduce of step i overlaps step i + 1
+    bool mean_on_ = false;
+    long long mean_total_ = 0;
+    double* mean_buf_[2] = {nullptr, nullptr};
+    double* mean_out_ = nullptr;
+    hipEvent_t dens_ready_[2] = {}, comm_done_[2] = {};
+    int mean_next_ = 0, mean_last_ = -1;
+    int nccl_fail(int rc, const char* what, std::string& err) const {
+        err = std::string(what) + ": " + (rccl_ && rccl_->error_string ? rccl_->error_string(rc) : "RCCL error");
+        return MSM_ERR_HIP;
+    }
+    // the density target of the step about to be enqueued / the collective behind the step just enqueued
+    int mean_step_open(std::string& err);
+    int mean_step_close(std::string& err);
+
     // optional per-launch timing (HIP events on the launch stream), bucketed by pass kind
     struct ProfRec { int kind; hipEvent_t a, b; };
     std::vector<ProfRec> prof_;
@@ -538,6 +566,22 @@ class Engine final : public IEngine {
 };
 
 void Engine::release() {
+    if (comm_) {
+        if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        (void)rccl_->comm_destroy(comm_);
+        comm_ = nullptr;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (mean_buf_[i]) (void)hipFree(mean_buf_[i]);
+        if (dens_ready_[i]) (void)hipEventDestroy(dens_ready_[i]);
+        if (comm_done_[i]) (void)hipEventDestroy(comm_done_[i]);
+        mean_buf_[i] = nullptr; dens_ready_[i] = comm_done_[i] = nullptr;
+    }
+    if (mean_out_) { (void)hipFree(mean_out_); mean_out_ = nullptr; }
+    if (comm_small_d_) { (void)hipFree(comm_small_d_); comm_small_d_ = nullptr; }
+    if (comm_small_h_) { (void)hipHostFree(comm_small_h_); comm_small_h_ = nullptr; }
+    if (comm_stream_) { (void)hipStreamDestroy(comm_stream_); comm_stream_ = nullptr; }
     if (copy_stream_) {
         (void)hipStreamSynchronize(copy_stream_);
         for (int i = 0; i < DL_SLOTS; ++i) {
@@ -669,6 +713,19 @@ int Engine::init(std::string& err) {
     };
     const size_t grid_bytes = n3_ * sizeof(cplx);
     const int pairs = (batch_ + 1) / 2;
+    {
+        // The large arrays are checked against the free memory first: an allocation beyond it does not always fail
+        // at hipMalloc, it can surface as an out-of-memory error of the first kernel that touches the array.
+        const size_t need = grid_bytes * ((size_t)ns_ + 2 * pairs + (lowdim_ ? 2 * pairs : pairs) + 1) +
+                            n3_ * sizeof(real) * (size_t)(2 * pairs) + sizeof(double) * (size_t)ns_ * ntiles_;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (need + ((size_t)64 << 20) > free_b) {
+            err = "device memory: " + std::to_string(need >> 20) + " MiB needed for " + std::to_string(ns_) + " streams, " +
+                  std::to_string(free_b >> 20) + " MiB free";
+            return MSM_ERR_NOMEM;
+        }
+    }
     HIP_TRY(dmalloc((void**)&P_, grid_bytes * ns_));
     HIP_TRY(dmalloc((void**)&X_, grid_bytes * (size_t)(2 * pairs)));
     HIP_TRY(dmalloc((void**)&W_, grid_bytes * (lowdim_ ? 2 * pairs : pairs)));   // dims < 3: one slot per stream
@@ -1126,6 +1183,7 @@ int Engine::step(std::string& err) {
     if (in_step_) { err = "msm_step inside an open msm_step_begin"; return MSM_ERR_STATE; }
     phi_s0_ = -1;   // the batch potential buffer is not maintained by steps
     enter_fourier();
+    if (int rc = mean_step_open(err)) return rc;
     auto body = [&]() -> hipError_t {
         if (step_dens_) { hipError_t e = hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_); if (e != hipSuccess) return e; }
         for_batches([&](int s0, int nb) {
@@ -1139,7 +1197,7 @@ int Engine::step(std::string& err) {
     // is captured once into a HIP graph and replayed.  Every argument of every launch is constant from step to step
     // (dt, flags and counters live in device memory); only the set of batches that still have a live stream and the
     // density target can change, and either re-captures.
-    if (graph_ok_ && !prof_on_ && n3_ * (size_t)ns_ <= GRAPH_MAX_CELLS) {
+    if (graph_ok_ && !prof_on_ && !mean_on_ && n3_ * (size_t)ns_ <= GRAPH_MAX_CELLS) {
         std::vector<char> key;
         for (int s0 = 0; s0 < ns_; s0 += batch_) {
             char any = 0;
@@ -1173,7 +1231,7 @@ int Engine::step(std::string& err) {
     }
     HIP_TRY(body());
     HIP_TRY(hipGetLastError());
-    return MSM_OK;
+    return mean_step_close(err);
 }
 
 int Engine::step_begin(const double* a_now, const double* tau_next, std::string& err) {
@@ -1211,12 +1269,13 @@ int Engine::step_end(const double* kick_a, const double* new_time, const double*
     HIP_TRY(hipMemcpyAsync(d_in_[2], stau.data(), sizeof(real) * ns_, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     phi_s0_ = -1;
+    if (int rc = mean_step_open(err)) return rc;
     if (step_dens_) HIP_TRY(hipMemsetAsync(step_dens_, 0, sizeof(double) * n3_, stream_));
     for_batches([&](int s0, int nb) { step_back(s0, nb, d_in_[0], d_in_[1], d_in_[2]); });
     publish();
     in_step_ = false;
     HIP_TRY(hipGetLastError());
-    return MSM_OK;
+    return mean_step_close(err);
 }
 
 int Engine::sync(std::string& err) {
@@ -1434,8 +1493,111 @@ int Engine::density_sum(void* dev_out, std::string& err) {
 }
 
 int Engine::step_density(void* dev_out, std::string& err) {
-    (void)err;
+    if (mean_on_) { err = "the step's density target belongs to msm_mean_density_begin on this context"; return MSM_ERR_STATE; }
     step_dens_ = (double*)dev_out;
+    return MSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// several GPUs
+// ---------------------------------------------------------------------------
+int Engine::comm_init(const void* id, int rank, int world, std::string& err) {
+    if (comm_) { err = "msm_comm_init called twice"; return MSM_ERR_STATE; }
+    if (!id || world < 1 || rank < 0 || rank >= world) { err = "bad communicator arguments"; return MSM_ERR_INVALID; }
+    rccl_ = rccl(err);
+    if (!rccl_) return MSM_ERR_INVALID;
+    CommId cid;
+    std::memcpy(cid.bytes, id, COMM_ID_BYTES);
+    const int rc = rccl_->comm_init_rank(&comm_, world, cid, rank);   // meets the other ranks
+    if (rc != 0) { comm_ = nullptr; return nccl_fail(rc, "ncclCommInitRank", err); }
+    comm_rank_ = rank; comm_world_ = world;
+    HIP_TRY(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&comm_small_d_, sizeof(double) * COMM_SMALL));
+    HIP_TRY(hipHostMalloc((void**)&comm_small_h_, sizeof(double) * COMM_SMALL));
+    return MSM_OK;
+}
+
+int Engine::mean_density_begin(long long total_streams, std::string& err) {
+    if (!comm_) { err = "msm_comm_init first"; return MSM_ERR_STATE; }
+    if (in_step_) { err = "inside an open msm_step_begin"; return MSM_ERR_STATE; }
+    if (total_streams < 1) { err = "total_streams must be >= 1"; return MSM_ERR_INVALID; }
+    mean_total_ = total_streams;
+    if (mean_on_) return MSM_OK;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc((void**)&mean_buf_[i], sizeof(double) * n3_));
+        HIP_TRY(hipEventCreateWithFlags(&dens_ready_[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&comm_done_[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipMalloc((void**)&mean_out_, sizeof(double) * n3_));
+    mean_on_ = true;
+    mean_next_ = 0; mean_last_ = -1;
+    step_dens_ = nullptr;
+    return MSM_OK;
+}
+
+int Engine::mean_step_open(std::string& err) {
+    if (!mean_on_) return MSM_OK;
+    // this buffer's previous all-reduce (two steps ago) must have left it before the step clears it
+    HIP_TRY(hipStreamWaitEvent(stream_, comm_done_[mean_next_], 0));
+    step_dens_ = mean_buf_[mean_next_];
+    return MSM_OK;
+}
+
+int Engine::mean_step_close(std::string& err) {
+    if (!mean_on_) return MSM_OK;
+    const int b = mean_next_;
+    HIP_TRY(hipEventRecord(dens_ready_[b], stream_));
+    HIP_TRY(hipStreamWaitEvent(comm_stream_, dens_ready_[b], 0));
+    // sum over the GPUs of sum_s |psi_s|^2 (synthesizer/src/lib.rs:217-229 in situ); runs beside the next step
+    const int rc = rccl_->all_reduce(mean_buf_[b], mean_buf_[b], n3_, COMM_F64, COMM_SUM, comm_, comm_stream_);
+    if (rc != 0) return nccl_fail(rc, "ncclAllReduce", err);
+    HIP_TRY(hipEventRecord(comm_done_[b], comm_stream_));
+    mean_last_ = b;
+    mean_next_ = b ^ 1;
+    return MSM_OK;
+}
+
+int Engine::mean_density(double* host, void** dev, std::string& err) {
+    if (!mean_on_) { err = "msm_mean_density_begin first"; return MSM_ERR_STATE; }
+    if (mean_last_ < 0) { err = "no step has been taken since msm_mean_density_begin"; return MSM_ERR_STATE; }
+    k_scale_f64<<<2048, 256, 0, comm_stream_>>>(mean_buf_[mean_last_], mean_out_, n3_, 1.0 / (double)mean_total_);
+    if (host) HIP_TRY(hipMemcpyAsync(host, mean_out_, sizeof(double) * n3_, hipMemcpyDeviceToHost, comm_stream_));
+    HIP_TRY(hipStreamSynchronize(comm_stream_));
+    if (dev) *dev = mean_out_;
+    return MSM_OK;
+}
+
+int Engine::comm_allreduce_f64(double* vals, int n, int op, std::string& err) {
+    if (!comm_) { err = "msm_comm_init first"; return MSM_ERR_STATE; }
+    if (!vals || n < 1 || n > COMM_SMALL) { err = "1 to 64 values"; return MSM_ERR_INVALID; }
+    if (op != COMM_SUM && op != COMM_MAX && op != COMM_MIN) { err = "op must be sum (0), max (2) or min (3)"; return MSM_ERR_INVALID; }
+    std::memcpy(comm_small_h_, vals, sizeof(double) * n);
+    HIP_TRY(hipMemcpyAsync(comm_small_d_, comm_small_h_, sizeof(double) * n, hipMemcpyHostToDevice, stream_));
+    const int rc = rccl_->all_reduce(comm_small_d_, comm_small_d_, (size_t)n, COMM_F64, op, comm_, stream_);
+    if (rc != 0) return nccl_fail(rc, "ncclAllReduce", err);
+    HIP_TRY(hipMemcpyAsync(comm_small_h_, comm_small_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::memcpy(vals, comm_small_h_, sizeof(double) * n);
+    return MSM_OK;
+}
+
+// The synthesizer's sums of one dump index over all GPUs (the reference gathers per-rank results over MPI,
+// synthesizer/src/lib.rs:466-583): one all-reduce of the four fields, one of the stream count.
+int Engine::synth_allreduce(int slot, std::string& err) {
+    if (!comm_) { err = "msm_comm_init first"; return MSM_ERR_STATE; }
+    if (slot < 0 || slot > 65535) { err = "synthesizer slot out of range"; return MSM_ERR_INVALID; }
+    if ((int)synth_.size() <= slot) synth_.resize(slot + 1);
+    SynthSlot& sl = synth_[slot];
+    if (!sl.sums) {   // a rank without seed streams contributes zeros
+        HIP_TRY(hipMalloc((void**)&sl.sums, sizeof(double2) * 4 * n3_));
+        HIP_TRY(hipMemsetAsync(sl.sums, 0, sizeof(double2) * 4 * n3_, stream_));
+        sl.count = 0;
+    }
+    int rc = rccl_->all_reduce(sl.sums, sl.sums, 8 * n3_, COMM_F64, COMM_SUM, comm_, stream_);
+    if (rc != 0) return nccl_fail(rc, "ncclAllReduce", err);
+    double c = (double)sl.count;
+    if (int r2 = comm_allreduce_f64(&c, 1, COMM_SUM, err)) return r2;   // synchronises the stream
+    sl.count = (long long)(c + 0.5);
     return MSM_OK;
 }
 

@@ -35,6 +35,11 @@ struct IEngine {
     virtual int synth_qx(int slot, double* re, double* im, std::string& err) = 0;
     virtual int synth_qx_noalloc(int slot, double* out2, std::string& err) = 0;
     virtual int synth_release(int slot, std::string& err) = 0;
+    virtual int comm_init(const void* id, int rank, int world, std::string& err) = 0;
+    virtual int mean_density_begin(long long total_streams, std::string& err) = 0;
+    virtual int mean_density(double* host, void** dev, std::string& err) = 0;
+    virtual int synth_allreduce(int slot, std::string& err) = 0;
+    virtual int comm_allreduce_f64(double* vals, int n, int op, std::string& err) = 0;
     virtual int timer_start(std::string& err) = 0;
     virtual int timer_stop(float* ms, std::string& err) = 0;
     virtual int profile(int enable, std::string& err) = 0;

@@ -5,7 +5,7 @@
 //
 //   msm-simulator --toml <path> [-v|--verbose] [--test]
 //                 [--expanding] [--precision f64|f32] [--device N] [--batch B] [--synthesize] [--resume]
-//                 [--rank R --world W]
+//                 [--rank R --world W [--comm-file PATH]] [--wave STREAMS]
 //
 // --expanding stands for the reference's cargo feature of the same name (compile-time there).
 // --synthesize also writes the msm-synthesizer's products (synthesizer/src/main.rs:63-187) for the seed
@@ -14,6 +14,13 @@
 //   are write-only, simulation_object.rs:627,915); streams without dumps start from the initial conditions.
 // --rank R --world W: this process evolves block R of the seed list split into W blocks (one process per GPU,
 //   streams are independent: main.rs:43-79); the mean-field run goes to rank 0.
+// --wave STREAMS: at most that many streams share the device at a time; the rest follow in further waves (the
+//   reference runs them one by one anyway).  Without it the driver starts with all of them and halves the wave
+//   whenever the device reports that it is out of memory.
+// --comm-file PATH (with --world W > 1): the W processes also join one RCCL communicator -- rank 0 publishes the
+//   128-byte id in PATH (a name unique to this launch, on a file system all ranks see), the others wait for it.
+//   They then stop together when a stream aliases anywhere, and --synthesize works across the ranks: the
+//   synthesizer's sums are all-reduced per dump index and rank 0 writes the -combined/ products.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -26,6 +33,7 @@
 #include <condition_variable>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/msm.h"
@@ -44,13 +52,14 @@ const char* SIM_DATA_FOLDER = "sim-data";           // simulation_object.rs:1116
 struct Args {
     std::string toml;
     bool verbose = false, test = false, expanding = false, synthesize = false, resume = false;
-    int precision = MSM_F64, device = 0, batch = 0, rank = 0, world = 1;
+    int precision = MSM_F64, device = 0, batch = 0, rank = 0, world = 1, wave = 0;
+    std::string comm_file;
 };
 
 [[noreturn]] void usage(const char* why) {
     std::fprintf(stderr, "error: %s\n\nUSAGE:\n    msm-simulator [OPTIONS] --toml <TOML>\n\nOPTIONS:\n"
                          "    -t, --toml <TOML>\n    -v, --verbose\n        --test\n        --expanding\n"
-                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n        --resume\n        --rank <R> --world <W>\n", why);
+                         "        --precision <f64|f32>\n        --device <N>\n        --batch <STREAMS>\n        --synthesize\n        --resume\n        --rank <R> --world <W> [--comm-file <PATH>]\n        --wave <STREAMS>\n", why);
     std::exit(2);
 }
 
@@ -71,6 +80,8 @@ Args parse_args(int argc, char** argv) {
         else if (s == "--resume") a.resume = true;
         else if (s == "--rank") a.rank = std::atoi(val().c_str());
         else if (s == "--world") a.world = std::atoi(val().c_str());
+        else if (s == "--comm-file") a.comm_file = val();
+        else if (s == "--wave") a.wave = std::atoi(val().c_str());
         else if (s == "--precision") { const std::string p = val(); if (p == "f64") a.precision = MSM_F64; else if (p == "f32") a.precision = MSM_F32; else usage("--precision takes f64 or f32"); }
         else if (s == "--device") a.device = std::atoi(val().c_str());
         else if (s == "--batch") a.batch = std::atoi(val().c_str());
@@ -78,7 +89,10 @@ Args parse_args(int argc, char** argv) {
     }
     if (a.toml.empty()) usage("The following required arguments were not provided: --toml <TOML>");
     if (a.world < 1 || a.rank < 0 || a.rank >= a.world) usage("--rank must lie in [0, --world)");
-    if (a.world > 1 && a.synthesize) usage("--synthesize needs every stream in one process; with several GPUs use the Python driver (msm_amd.synth)");
+    if (a.world > 1 && a.synthesize && a.comm_file.empty()) usage("--synthesize over several processes needs --comm-file (the ranks' sums are all-reduced)");
+    if (a.world == 1 && !a.comm_file.empty()) usage("--comm-file goes with --world W > 1");
+    // a resumed stream has passed dumps whose ensemble sums were never formed in this process
+    if (a.resume && a.synthesize) usage("--resume cannot be combined with --synthesize");
     return a;
 }
 
@@ -118,21 +132,12 @@ class DumpWriters {
     std::vector<std::future<void>> active_;
 };
 
+// One device context's worth of streams, start to finish.  `nomem` reports that the device could not hold them
+// (nothing has been written then): the caller retries with fewer streams per wave.
 template <typename T>
-int run(const Args& args) {
-    const auto t_start = std::chrono::steady_clock::now();
-    const TomlParameters toml = read_toml(args.toml, args.expanding);
-    std::vector<StreamSpec> streams = simulation_iter(toml);
-    if (args.world > 1) {
-        // block partition of the seed streams (ceil(n / world) each); the trailing mean-field run stays with rank 0
-        const size_t n_seed = streams.size() - 1, per = (n_seed + args.world - 1) / args.world;
-        const size_t first = std::min(per * (size_t)args.rank, n_seed), last = std::min(first + per, n_seed);
-        std::vector<StreamSpec> mine(streams.begin() + first, streams.begin() + last);
-        if (args.rank == 0) mine.push_back(streams.back());
-        streams.swap(mine);
-        if (streams.empty()) { std::printf("rank %d of %d: no streams\n", args.rank, args.world); return 0; }
-    }
-    const bool multi_stream = streams.size() - 1 > 1;   // SimulationIter::len() counts the seeds (io.rs:121-125)
+int run_wave(const Args& args, const TomlParameters& toml, const std::vector<StreamSpec>& streams, bool& nomem) {
+    nomem = false;
+    const bool lead = args.rank == 0;   // holds the mean-field run and writes the ensemble products
     const int ns = (int)streams.size();
     double particle_mass, hbar_;
     determine_pmass_hbar_(toml, particle_mass, hbar_);
@@ -166,7 +171,44 @@ int run(const Args& args) {
         cfg.max_dloga = toml.cosmology->max_dloga.value_or(0.0);
     }
     msm_ctx* ctx = nullptr;
-    if (msm_create(&cfg, &ctx) != MSM_OK) throw std::runtime_error(std::string("msm_create failed: ") + msm_last_error(nullptr));
+    if (const int rc = msm_create(&cfg, &ctx); rc != MSM_OK) {
+        if (rc == MSM_ERR_NOMEM) { nomem = true; return 0; }
+        throw std::runtime_error(std::string("msm_create failed: ") + msm_last_error(nullptr));
+    }
+
+    // ---- several processes: one RCCL communicator (include/msm.h: msm_comm_*)
+    const bool comm = !args.comm_file.empty();
+    if (comm) {
+        unsigned char id[MSM_COMM_ID_BYTES];
+        if (lead) {
+            if (msm_comm_unique_id(id) != MSM_OK) throw std::runtime_error(std::string("msm_comm_unique_id failed: ") + msm_last_error(nullptr));
+            const std::string tmp = args.comm_file + ".tmp";
+            FILE* f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) throw std::runtime_error("cannot write " + tmp);
+            std::fclose(f);
+            std::filesystem::rename(tmp, args.comm_file);   // appears complete or not at all
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                std::error_code ec;
+                if (std::filesystem::file_size(args.comm_file, ec) == sizeof id && !ec) {
+                    FILE* f = std::fopen(args.comm_file.c_str(), "rb");
+                    const bool ok = f && std::fread(id, 1, sizeof id, f) == sizeof id;
+                    if (f) std::fclose(f);
+                    if (ok) break;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) throw std::runtime_error("no communicator id appeared in " + args.comm_file);
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        }
+        check(ctx, msm_comm_init(ctx, id, args.rank, args.world), "msm_comm_init");
+        if (lead) std::filesystem::remove(args.comm_file);   // every rank has joined: the id is spent
+    }
+    // values every rank must agree on before it acts (op: RCCL's 0 sum, 2 max, 3 min)
+    auto agree = [&](double v, int op) {
+        if (comm) check(ctx, msm_comm_allreduce_f64(ctx, &v, 1, op), "msm_comm_allreduce_f64");
+        return v;
+    };
 
     double derived[8];
     check(ctx, msm_get_derived(ctx, derived), "msm_get_derived");
@@ -260,28 +302,43 @@ int run(const Args& args) {
             writers.submit<T>(dir + name, std::move(phi), std::move(zero), shape);
         }
     };
-    // ---- in-situ synthesizer (synthesizer/src/main.rs:63-187): seed streams only, the last entry is the mean-field run
-    const int n_seed_streams = ns - 1;
+    // ---- in-situ synthesizer (synthesizer/src/main.rs:63-187): seed streams only (the mean-field run is the last
+    // entry on the lead rank).  A stream adds itself to the slot of a dump index when it gets there; a slot is
+    // finished -- summed over the ranks, averaged, written by the lead rank -- once every rank's seed streams have.
+    int n_seed_streams = 0;
+    for (const StreamSpec& sp : streams) n_seed_streams += sp.sampled ? 1 : 0;   // they come first; the mean-field run is last
     std::vector<int> synth_count(toml.num_data_dumps + 1, 0);
     std::vector<std::pair<double, double>> qx(toml.num_data_dumps + 1, {0.0, 0.0});
     std::vector<char> qx_done(toml.num_data_dumps + 1, 0);
+    int synth_next = 0;
     const std::string combined = std::string(SIM_DATA_FOLDER) + "/" + toml.sim_name + "-combined";
     auto synthesize = [&](int s, int k) {
         if (!args.synthesize || s >= n_seed_streams || k < 0 || k > (int)toml.num_data_dumps) return;
         check(ctx, msm_synth_accumulate(ctx, s, k), "msm_synth_accumulate");
-        if (++synth_count[k] < n_seed_streams) return;
-        std::filesystem::create_directories(combined);
-        static const char* fields[4] = {"psi", "psi2", "psik", "psik2"};
-        for (int f = 0; f < 4; ++f) {
-            char name[64];
-            std::snprintf(name, sizeof name, "/%s_%05d", fields[f], k);
-            std::vector<double> re(n_cells), im(n_cells);
-            check(ctx, msm_synth_fetch(ctx, k, f, re.data(), im.data()), "msm_synth_fetch");
-            writers.submit<double>(combined + name, std::move(re), std::move(im), shape);
+        ++synth_count[k];
+    };
+    // collective when there is a communicator: every rank calls it once per loop iteration
+    auto flush_synth = [&]() {
+        if (!args.synthesize || n_seed_streams + (comm ? 1 : 0) <= 0) return;
+        for (; synth_next <= (int)toml.num_data_dumps; ++synth_next) {
+            const int k = synth_next;
+            if (agree(synth_count[k] == n_seed_streams ? 1.0 : 0.0, 3) < 0.5) break;
+            if (comm) check(ctx, msm_synth_allreduce(ctx, k), "msm_synth_allreduce");
+            if (lead) {
+                std::filesystem::create_directories(combined);
+                static const char* fields[4] = {"psi", "psi2", "psik", "psik2"};
+                for (int f = 0; f < 4; ++f) {
+                    char name[64];
+                    std::snprintf(name, sizeof name, "/%s_%05d", fields[f], k);
+                    std::vector<double> re(n_cells), im(n_cells);
+                    check(ctx, msm_synth_fetch(ctx, k, f, re.data(), im.data()), "msm_synth_fetch");
+                    writers.submit<double>(combined + name, std::move(re), std::move(im), shape);
+                }
+                check(ctx, msm_synth_qx(ctx, k, &qx[k].first, &qx[k].second), "msm_synth_qx");
+                qx_done[k] = 1;
+            }
+            check(ctx, msm_synth_release(ctx, k), "msm_synth_release");
         }
-        check(ctx, msm_synth_qx(ctx, k, &qx[k].first, &qx[k].second), "msm_synth_qx");
-        qx_done[k] = 1;
-        check(ctx, msm_synth_release(ctx, k), "msm_synth_release");
     };
     // ---- restart: last complete dump of every stream (both planes present and of the right shape)
     std::vector<int> resumed(ns, -1);
@@ -310,6 +367,7 @@ int run(const Args& args) {
         }
     }
     for (int s = 0; s < ns; ++s) if (resumed[s] < 0) { dump(s, 0); synthesize(s, 0); }   // main.rs:61
+    flush_synth();
 
     // ---- expanding-box host state (simulation_object.rs:726-760, :939-990)
     std::vector<ScaleFactorSolver> solvers;
@@ -336,10 +394,26 @@ int run(const Args& args) {
     check(ctx, msm_get_status(ctx, prev.data(), ns), "msm_get_status");
     const auto t_loop = std::chrono::steady_clock::now();
     const T tf = (T)toml.final_sim_time, nd = (T)toml.num_data_dumps;
+    bool aliased_here = false;
     for (;;) {
         bool any_active = false;
         for (int s = 0; s < ns; ++s) any_active = any_active || prev[s].active;
-        if (!any_active) break;   // main.rs:65: while not_finished()
+        if (comm) {
+            // one exchange per iteration: "a stream is still running somewhere" and "a stream aliased somewhere".  All
+            // ranks leave the loop in the same iteration; none is left waiting in a collective the others never enter.
+            double flags[2] = {any_active ? 1.0 : 0.0, aliased_here ? 1.0 : 0.0};
+            check(ctx, msm_comm_allreduce_f64(ctx, flags, 2, 2), "msm_comm_allreduce_f64");
+            if (flags[1] > 0.5) {
+                writers.drain(true);
+                if (!aliased_here) std::fprintf(stderr, "rank %d: stopping, a stream on another rank aliased\n", args.rank);
+                msm_destroy(ctx);
+                return 101;
+            }
+            if (flags[0] < 0.5) break;
+            if (!any_active) { flush_synth(); continue; }   // idle here, others still stepping: stay in the exchanges
+        } else if (!any_active) {
+            break;   // main.rs:65: while not_finished()
+        }
         if (!args.expanding) {
             check(ctx, msm_step(ctx), "msm_step");
         } else {
@@ -374,10 +448,12 @@ int run(const Args& args) {
             if (st[s].n_steps == prev[s].n_steps) continue;   // stream was already finished
             if (st[s].aliased) {
                 // the reference panics here (simulation_object.rs:607-617)
-                writers.drain(true);
                 std::fprintf(stderr, "thread 'main' panicked at 'simulation aliased Fourier aliasing occurred; p_mass is %g and the "
                                      "threshold was set at %g with k2_cutoff = %g' (%s)\n",
                              st[s].alias_mass, toml.alias_threshold, toml.k2_cutoff, streams[s].sim_name.c_str());
+                aliased_here = true;
+                if (comm) break;          // the other ranks learn of it at the next exchange; all exit there
+                writers.drain(true);
                 msm_destroy(ctx);
                 return 101;
             }
@@ -394,8 +470,9 @@ int run(const Args& args) {
                             (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_loop).count());
         }
         prev = st;
+        flush_synth();
     }
-    if (args.synthesize && n_seed_streams > 0) {
+    if (args.synthesize && lead && n_seed_streams > 0) {
         // Qx time series over the dumps (post_combine, synthesizer/src/lib.rs:351-609), shape (n_dumps + 1, 1, 1, 1)
         std::vector<double> re, im;
         for (size_t k = 0; k < qx.size(); ++k)
@@ -409,6 +486,48 @@ int run(const Args& args) {
     for (auto& b : pool.free) { msm_host_free(b.first); msm_host_free(b.second); }
     pool.free.clear();
     msm_destroy(ctx);
+    return 0;
+}
+
+template <typename T>
+int run(const Args& args) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const TomlParameters toml = read_toml(args.toml, args.expanding);
+    std::vector<StreamSpec> streams = simulation_iter(toml);
+    if (args.world > 1) {
+        // block partition of the seed streams (ceil(n / world) each); the trailing mean-field run stays with rank 0
+        const size_t n_seed = streams.size() - 1, per = (n_seed + args.world - 1) / args.world;
+        const size_t first = std::min(per * (size_t)args.rank, n_seed), last = std::min(first + per, n_seed);
+        std::vector<StreamSpec> mine(streams.begin() + first, streams.begin() + last);
+        if (args.rank == 0) mine.push_back(streams.back());
+        streams.swap(mine);
+        if (!args.comm_file.empty() && last == first) throw std::runtime_error("--comm-file: more ranks than seed streams");
+        if (streams.empty()) { std::printf("rank %d of %d: no streams\n", args.rank, args.world); return 0; }
+    }
+    const bool multi_stream = streams.size() > 2;   // SimulationIter::len() counts the seeds (io.rs:121-125)
+    // The reference runs its simulations one after the other (main.rs:43-79), so any grouping of them is legal: all
+    // at once when the device holds them, otherwise in waves of as many as fit (halved until msm_create succeeds).
+    size_t wave = streams.size();
+    if (args.wave > 0 && (size_t)args.wave < wave) {
+        if (args.synthesize || !args.comm_file.empty()) throw std::runtime_error("--wave cannot be combined with --synthesize or --comm-file");
+        wave = (size_t)args.wave;
+    }
+    for (size_t w0 = 0; w0 < streams.size();) {
+        const size_t w1 = std::min(w0 + wave, streams.size());
+        const std::vector<StreamSpec> part(streams.begin() + w0, streams.begin() + w1);
+        bool nomem = false;
+        const int rc = run_wave<T>(args, toml, part, nomem);
+        if (nomem) {
+            if (wave == 1) throw std::runtime_error(std::string("msm_create failed: ") + msm_last_error(nullptr));
+            if (args.synthesize || !args.comm_file.empty())
+                throw std::runtime_error("the device cannot hold this process's streams at once, which --synthesize and --comm-file need: use more ranks");
+            wave = (wave + 1) / 2;
+            std::printf("device memory holds fewer than %zu streams of this size: running in waves of %zu\n", w1 - w0, wave);
+            continue;
+        }
+        if (rc != 0) return rc;
+        w0 = w1;
+    }
     if (multi_stream)
         std::printf("Finished all streams in %lld seconds\n",
                     (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count());

@@ -241,6 +241,45 @@ class Evolver:
     def synth_release(self, slot: int):
         self._check(self._lib.msm_synth_release(self._ctx, slot), "msm_synth_release")
 
+    # -- several GPUs (RCCL inside the library) -------------------------------
+    COMM_SUM, COMM_MAX, COMM_MIN = 0, 2, 3
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes one rank creates and hands to every other rank (msm_comm_unique_id)."""
+        lib = L.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.msm_comm_unique_id(buf)
+        if rc != 0:
+            raise MsmError(f"msm_comm_unique_id failed ({rc}): {lib.msm_last_error(None).decode()}")
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        if len(comm_id) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        self._check(self._lib.msm_comm_init(self._ctx, comm_id, rank, world), "msm_comm_init")
+
+    def comm_allreduce(self, values, op: int = 0):
+        arr = (C.c_double * len(values))(*[float(v) for v in values])
+        self._check(self._lib.msm_comm_allreduce_f64(self._ctx, arr, len(values), op), "msm_comm_allreduce_f64")
+        return list(arr)
+
+    def mean_density_begin(self, total_streams: int):
+        self._check(self._lib.msm_mean_density_begin(self._ctx, total_streams), "msm_mean_density_begin")
+
+    def mean_density(self, to_host: bool = True):
+        """<|psi|^2> over all ranks' streams after the most recent step: numpy array, or the device pointer."""
+        dev = C.c_void_p()
+        if not to_host:
+            self._check(self._lib.msm_mean_density(self._ctx, None, C.byref(dev)), "msm_mean_density")
+            return dev.value
+        out = np.empty(self.shape, dtype=np.float64)
+        self._check(self._lib.msm_mean_density(self._ctx, out.ctypes.data, C.byref(dev)), "msm_mean_density")
+        return out
+
+    def synth_allreduce(self, slot: int):
+        self._check(self._lib.msm_synth_allreduce(self._ctx, slot), "msm_synth_allreduce")
+
     def timer_start(self):
         self._check(self._lib.msm_timer_start(self._ctx), "msm_timer_start")
 

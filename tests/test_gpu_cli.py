@@ -344,3 +344,34 @@ def test_gaussian_overdensity_mft_example(tmp_path):
     assert len(sims) == 1 and len(sims[0].dumps) == 3 and sims[0].parameters.n_steps >= 3
     for k, psi in sims[0].dumps:
         assert rel(load_dump(tmp_path, "gaussian-overdensity-512-mft", k), psi) < 1e-11, k
+
+
+def test_streams_in_waves(tmp_path):
+    # --wave: the 3 seed streams + mean-field run through the device two at a time give the dumps of the run that
+    # holds all four at once (the reference runs them one after the other anyway, main.rs:43-79)
+    cfg = dict(TOPHAT, sampling=dict(seeds="1 to 3", scheme="Husimi"))
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    run_cli(one, cfg)
+    r = run_cli(two, cfg, "--wave", "2")
+    assert "Finished all streams" in r.stdout
+    for n in ["spherical-tophat-stream00001", "spherical-tophat-stream00002", "spherical-tophat-stream00003", "spherical-tophat"]:
+        for k in range(6):
+            assert rel(load_dump(two, n, k), load_dump(one, n, k)) < 1e-12, (n, k)
+    run_cli(two, cfg, "--wave", "2", "--synthesize", expect=1)
+
+
+def test_more_streams_than_the_device_holds_run_in_waves(tmp_path):
+    # 512^3 fp32 x 400 streams is 400 GiB of state: msm_create reports MSM_ERR_NOMEM and the driver halves the wave
+    # until the device holds it (--test: initial conditions and sampling of every wave, no evolution)
+    cfg = dict(TOPHAT, size=512, sampling=dict(seeds="1 to 399", scheme="Husimi"))
+    r = run_cli(tmp_path, cfg, "--test", "--precision", "f32")
+    assert "running in waves of" in r.stdout
+
+
+def test_two_ranks_over_rccl_need_two_gpus_but_one_rank_world_works(tmp_path):
+    # --comm-file with --world 2 on a one-GPU box cannot form its communicator; the argument checks around it can run
+    cfg = dict(TOPHAT, sampling=dict(seeds="1 to 2", scheme="Husimi"))
+    run_cli(tmp_path, cfg, "--comm-file", str(tmp_path / "id"), expect=2)                       # needs --world > 1
+    run_cli(tmp_path, cfg, "--synthesize", "--rank", "0", "--world", "2", expect=2)             # needs --comm-file
+    run_cli(tmp_path, cfg, "--resume", "--synthesize", expect=2)
