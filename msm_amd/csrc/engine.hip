@@ -299,6 +299,7 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
 
 #include "kernels_generic.inc"
 #include "kernels_two_pass.inc"
+#include "kernels_two_pass_512.inc"
 #include "kernels_scalar.inc"
 #include "kernels_unfused.inc"
 
@@ -495,7 +496,13 @@ class Engine final : public IEngine {
     int mix_lpw_ = 1;
     cplx *chirp_ = nullptr, *bhat_ = nullptr, *twm_ = nullptr;
     template <int SGN> void launch_any(int ax, const PsiArgs& a, int nblk_y, int kind);
-    bool two_pass_ = false;  // every 3-D transform in two passes (N = 256); P_ then holds S = pass A of psi between steps
+    bool two_pass_ = false;  // every 3-D transform in two passes (N = 256; 512 in single precision); P_ then holds S = pass A of psi between steps
+    bool tq_ = false;        // two_pass_ with the 512^3 tiling (kernels_two_pass_512.inc)
+    int tp_a_tiles_ = 0, tp_b_blocks_ = 0;   // workgroups per grid of the pass-A / pass-B kernels
+    // With S = A[psi] as the state: psi = A^-1[S] / N_A and S' = B^-1[D B[S]] / N_B, where N_A, N_B are the numbers of
+    // points the two passes transform over (N_A N_B = N^3; both equal N^{3/2} at 256^3, 16384 and 8192 at 512^3);
+    // psi_k = B[S] / N^{3/2} either way.
+    real tp_scale_a_ = 0, tp_scale_b_ = 0;
     cplx* stage_ = nullptr;  // one grid: download staging
     bool in_step_ = false;
     // captured static step of small grids
@@ -641,7 +648,7 @@ int Engine::init(std::string& err) {
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
     if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
-    if (N_ == tp::N && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
+    if ((N_ == tp::N || N_ == 512) && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
     if (batch_ > GENERIC_MAX_BATCH) batch_ = GENERIC_MAX_BATCH;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
@@ -695,7 +702,20 @@ int Engine::init(std::string& err) {
     if (const char* e = getenv("MSM_GRAPH")) graph_ok_ = atoi(e) != 0;     // 0: plain launches for small grids too
     if (!own_stream_ && stream_ == nullptr) graph_ok_ = false;               // the legacy default stream cannot be captured
     two_pass_ = (N_ == tp::N) && dims_ == 3;
-    if (const char* e = getenv("MSM_TWO_PASS")) two_pass_ = two_pass_ && atoi(e) != 0;   // 0: the generic three-pass engine
+    const char* tp_env = getenv("MSM_TWO_PASS");
+    if (tp_env) two_pass_ = two_pass_ && atoi(tp_env) != 0;   // 0: the generic three-pass engine
+#ifdef MSM_TQ
+    // The single-precision 512^3 tiling is built and parity-tested but not selected by default: its tiles share only
+    // 64-byte blocks, each workgroup touches the two halves of a block tens of microseconds apart, and the step is
+    // slower than with three passes (measurements: tools/bench_c5.py).  MSM_TWO_PASS=2 selects it.
+    tq_ = N_ == tq::N && dims_ == 3 && tp_env && atoi(tp_env) == 2;
+    two_pass_ = two_pass_ || tq_;
+    static_assert(tq::MAX_BATCH == tp::MAX_BATCH, "one clamp serves both tilings");
+#endif
+    tp_a_tiles_ = tq_ ? 4096 : tp::A_TILES;
+    tp_b_blocks_ = tq_ ? 4096 : tp::B_BLOCKS;
+    tp_scale_a_ = tq_ ? (real)(1.0 / 16384.0) : c_.unit_scale;
+    tp_scale_b_ = tq_ ? (real)(1.0 / 8192.0) : c_.unit_scale;
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     ntiles_ = pw_blocks_;
     if (!anyn_) dispatch_n(N_, [&](auto nc) {
@@ -932,6 +952,17 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
     const int pairs = (nb + 1) / 2;
     const PoisArgs p = pois_args(s0, nb, act);
     if (two_pass_) {
+#ifdef MSM_TQ
+        if (tq_) {
+            timed(PK_POISSON_Z, [&] { k5_poisson_b<<<dim3(tq::B_BLOCKS, (unsigned)pairs), dim3(tq::THREADS), 0, stream_>>>(p); });
+            const dim3 grid(tq::A_TILES, (unsigned)pairs), block(tq::THREADS);
+            if (with_x) timed(PK_PHI_X, [&] {
+                if (store_phi && track_max) k5_phi_out<1, 1><<<grid, block, 0, stream_>>>(p);
+                else if (store_phi) k5_phi_out<1, 0><<<grid, block, 0, stream_>>>(p);
+                else k5_phi_out<0, 1><<<grid, block, 0, stream_>>>(p);
+            });
+        } else
+#endif
         {
             timed(PK_POISSON_Z, [&] { k_poisson_b<<<dim3(tp::B_BLOCKS, (unsigned)pairs), dim3(tp::B_THREADS), 0, stream_>>>(p); });
             const dim3 grid(tp::A_TILES, (unsigned)pairs), block(tp::A_THREADS);
@@ -941,7 +972,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
                 else k_phi_max3<<<dim3(tp::A_TILES), block, 0, stream_>>>(p);
             });
         }
-        if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::A_TILES, s0, act);
+        if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp_a_tiles_, s0, act);
         if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
         return;
     }
@@ -971,7 +1002,11 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
     PoisArgs p = pois_args(s0, nb, act);
     p.X = X; p.x_local = local ? 1 : 0;
     if (two_pass_) {
-                    timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+#ifdef MSM_TQ
+        if (tq_) timed(PK_RHO_X, [&] { k5_rho_pass<<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tq::THREADS), 0, stream_>>>(p); });
+        else
+#endif
+        timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
     } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
@@ -984,7 +1019,19 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
 void Engine::psi_rt(const cplx* src, cplx* dst, bool alias, int s0, int n, const int* act, int kind) {
     PsiBArgs b{};
     b.src = src; b.dst = dst; b.n3 = n3_; b.active = act; b.s0 = s0; b.tw = tw_; b.drift = st_.drift; b.ksq = ksq_;
-    b.scale = c_.unit_scale; b.alias_cut = c_.alias_cut; b.fourpi2 = c_.fourpi2; b.partial = partial_; b.ntiles = ntiles_;
+    b.scale = tp_scale_b_; b.alias_cut = c_.alias_cut; b.fourpi2 = c_.fourpi2; b.partial = partial_; b.ntiles = ntiles_;
+    // the aliased mass is that of the unitary psi_k = B[S] D / N^{3/2}; the kernel sums |B[S] D / N_B|^2
+    b.alias_scale = (double)(c_.unit_scale / tp_scale_b_) * (double)(c_.unit_scale / tp_scale_b_);
+#ifdef MSM_TQ
+    if (tq_) {
+        const dim3 grid(tq::B_BLOCKS, (unsigned)n), block(tq::THREADS);
+        timed(kind, [&] {
+            if (alias) k5_psi_rt<1><<<grid, block, 0, stream_>>>(b);
+            else k5_psi_rt<0><<<grid, block, 0, stream_>>>(b);
+        });
+        return;
+    }
+#endif
     const dim3 grid(tp::B_BLOCKS, (unsigned)n), block(tp::B_THREADS);
     timed(kind, [&] {
         if (alias) k_psi_rt<1><<<grid, block, 0, stream_>>>(b);
@@ -995,13 +1042,26 @@ void Engine::psi_rt(const cplx* src, cplx* dst, bool alias, int s0, int n, const
 void Engine::psi_b_fwd(const cplx* src, cplx* dst, int s0, int n) {
     PsiBArgs b{};
     b.src = src; b.dst = dst; b.n3 = n3_; b.active = nullptr; b.s0 = s0; b.tw = tw_; b.scale = c_.unit_scale;
+#ifdef MSM_TQ
+    if (tq_) { timed(PK_PLAIN, [&] { k5_psi_b_fwd<<<dim3(tq::B_BLOCKS, (unsigned)n), dim3(tq::THREADS), 0, stream_>>>(b); }); return; }
+#endif
     timed(PK_PLAIN, [&] { k_psi_b_fwd<<<dim3(tp::B_BLOCKS, (unsigned)n), dim3(tp::B_THREADS), 0, stream_>>>(b); });
 }
 
 void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst_local, int s0, int n, const int* act) {
     PsiArgs a{};
     a.src = src; a.dst = dst; a.n3 = n3_; a.active = act; a.s0 = s0; a.src_local = src_local; a.dst_local = dst_local;
-    a.tw = tw_; a.scale = c_.unit_scale;
+    a.tw = tw_; a.scale = tp_scale_a_;
+#ifdef MSM_TQ
+    if (tq_) {
+        const dim3 grid(tq::A_TILES, (unsigned)n), block(tq::THREADS);
+        timed(PK_PLAIN, [&] {
+            if (sgn < 0) k5_psi_a<-1><<<grid, block, 0, stream_>>>(a);
+            else k5_psi_a<+1><<<grid, block, 0, stream_>>>(a);
+        });
+        return;
+    }
+#endif
     {
         const dim3 grid(tp::A_TILES, (unsigned)n), block(tp::A_THREADS);
         timed(PK_PLAIN, [&] {
@@ -1094,33 +1154,51 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
 
     if (lowdim_) { lowdim_step_back(s0, nb, nt, ntau, stau); return; }
     if (two_pass_) {
-        {
-            const dim3 gridA(tp::A_TILES), gridAp(tp::A_TILES, (unsigned)((nb + 1) / 2)), blockA(tp::A_THREADS);
-            // The whole step runs in place on the batch's states S (contiguous in P_): every kernel reads a tile or a
-            // run completely before it stores it, and tiles and runs are disjoint between workgroups.
-            cplx* S = P_ + (size_t)s0 * n3_;
-            p.X = S; p.Xout = S;
-            // psi = F^-1[ D psi_k ]: round trip of S through pass B with the whole drift factor in between, then
-            // pass A^-1 fused with rho and the Poisson pass A
-            psi_rt(S, S, false, s0, nb, st_.active, PK_INV_Z);
-            timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p); });
-            poisson_tail(s0, nb, false, false, false);
-            // kick between the two A passes; the second round trip applies the second drift, sums the aliased mass
-            // and leaves the new state
-            timed(PK_FWD_X, [&] { k_kick3<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); });
-            psi_rt(S, S, true, s0, nb, st_.active, PK_FWDZ_INVZ);
-            k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp::B_BLOCKS, s0, st_.active);
-            k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
-            // potential of psi(t + dt) straight from the state, for every stream that took the step (one that has
-            // just reached the final time included: its last density belongs to msm_step_density's product)
-            p.dens = step_dens_;
-            p.active = st_.stepped;
+        const dim3 gridA(tp_a_tiles_), gridAp(tp_a_tiles_, (unsigned)((nb + 1) / 2)), blockA(tq_ ? 512 : tp::A_THREADS);
+        // one launch of the fused inverse-x / density / Poisson-forward pass, and of the kick pass, in either tiling
+        auto invx_rho = [&](bool dens) {
             timed(PK_INVX_RHO, [&] {
-                if (step_dens_) k_invx_rho3<1><<<gridA, blockA, 0, stream_>>>(p);
+#ifdef MSM_TQ
+                if (tq_) {
+                    if (dens) k5_invx_rho<1><<<gridA, blockA, 0, stream_>>>(p);
+                    else k5_invx_rho<0><<<gridA, blockA, 0, stream_>>>(p);
+                    return;
+                }
+#endif
+                if (dens) k_invx_rho3<1><<<gridA, blockA, 0, stream_>>>(p);
                 else k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p);
             });
-            poisson_tail(s0, nb, false, true, true, st_.stepped);
-        }
+        };
+        auto kick = [&] {
+            timed(PK_FWD_X, [&] {
+#ifdef MSM_TQ
+                if (tq_) { k5_kick<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); return; }
+#endif
+                k_kick3<<<gridAp, blockA, 0, stream_>>>(p, st_.kick);
+            });
+        };
+        // The whole step runs in place on the batch's states S (contiguous in P_): every kernel reads a tile or a
+        // run completely before it stores it, and tiles and runs are disjoint between workgroups.
+        cplx* S = P_ + (size_t)s0 * n3_;
+        p.X = S; p.Xout = S;
+        p.scale = tp_scale_a_;
+        // psi = F^-1[ D psi_k ]: round trip of S through pass B with the whole drift factor in between, then
+        // pass A^-1 fused with rho and the Poisson pass A
+        psi_rt(S, S, false, s0, nb, st_.active, PK_INV_Z);
+        invx_rho(false);
+        poisson_tail(s0, nb, false, false, false);
+        // kick between the two A passes; the second round trip applies the second drift, sums the aliased mass
+        // and leaves the new state
+        kick();
+        psi_rt(S, S, true, s0, nb, st_.active, PK_FWDZ_INVZ);
+        k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp_b_blocks_, s0, st_.active);
+        k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+        // potential of psi(t + dt) straight from the state, for every stream that took the step (one that has
+        // just reached the final time included: its last density belongs to msm_step_density's product)
+        p.dens = step_dens_;
+        p.active = st_.stepped;
+        invx_rho(step_dens_ != nullptr);
+        poisson_tail(s0, nb, false, true, true, st_.stepped);
         return;
     }
 
@@ -1307,7 +1385,13 @@ int Engine::potential(int first, int count, std::string& err) {
         {
             PoisArgs p = pois_args(first, count, all_active_);
             p.X = P_ + (size_t)first * n3_;
-            timed(PK_INVX_RHO, [&] { k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+            p.scale = tp_scale_a_;
+            timed(PK_INVX_RHO, [&] {
+#ifdef MSM_TQ
+                if (tq_) { k5_invx_rho<0><<<dim3(tq::A_TILES), dim3(tq::THREADS), 0, stream_>>>(p); return; }
+#endif
+                k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
+            });
         }
         poisson_tail(first, count, true, true, true, all_active_);
     } else if (fourier_) {

@@ -183,11 +183,14 @@ def test_two_pass_256_expanding_vs_numpy_oracle(oracle_256_expanding, precision,
             assert rel_err(ev.get_psik(s), psik[s]) < tol, s
 
 
-def test_512_f32_expanding_step_vs_oracle():
+@pytest.mark.parametrize("two_pass", [0, 2], ids=["three-pass", "two-pass"])
+def test_512_f32_expanding_step_vs_oracle(two_pass):
     """One expanding step of one stream at 512^3 in single precision (the per-GPU grid of the largest benchmark
-    configuration) against the oracle run in the same precision."""
+    configuration) against the oracle run in the same precision, on the generic engine (the default at this size) and
+    on the two-pass tiling (MSM_TWO_PASS=2)."""
     N = 512
     o.FFT_WORKERS = 8
+    os.environ["MSM_TWO_PASS"] = str(two_pass)
     try:
         sims = oracle_sims(COSMO_BASE, N, 1, np.float32, expanding=True)
         with Evolver(size=N, n_streams=1, precision="f32", **evolver_kwargs(COSMO_BASE, True)) as ev:
@@ -197,7 +200,60 @@ def test_512_f32_expanding_step_vs_oracle():
             assert abs(st.dt / float(infos[0]["dt"]) - 1) <= 2e-6 and bool(st.dump) == infos[0]["dump"]
             assert abs(st.max_phi / float(infos[0]["max_phi"]) - 1) <= 1e-4
             assert abs(st.time / float(infos[0]["time"]) - 1) <= 2e-6 and st.aliased == 0
+            assert ev.derived()["transform_passes_mode"] == float(two_pass)
             assert rel_err(ev.get_psi(0), sims[0].psi) < 2e-4
             assert rel_err(ev.get_psik(0), sims[0].psik) < 2e-4
     finally:
         o.FFT_WORKERS = 0
+        os.environ.pop("MSM_TWO_PASS", None)
+
+
+def _run_512(mode, cosmology):
+    """Three single-precision streams at 512^3 in sub-batches of two (a pair and an unpaired stream), two steps."""
+    N = 512
+    os.environ["MSM_TWO_PASS"] = str(mode)
+    try:
+        base = dict(TOPHAT, cfl=0.05)
+        with Evolver(size=N, n_streams=3, batch_streams=2, cosmology=cosmology, precision="f32", **base) as ev:
+            assert ev.derived()["transform_passes_mode"] == float(mode)
+            rng = np.random.default_rng(7)
+            for s in range(3):
+                psi = (1.0 + 0.02 * rng.standard_normal((N, N, N), dtype=np.float32)
+                       + 0.02j * rng.standard_normal((N, N, N), dtype=np.float32)).astype(np.complex64)
+                psi *= np.float32(1.0 / np.sqrt(np.sum(np.abs(psi).astype(np.float64) ** 2) * ev.derived()["dx"] ** 3))
+                ev.set_psi(s, psi)
+            rows = []
+            for i in range(2):
+                if cosmology:
+                    ev.step_begin([0.5] * 3, [1e9] * 3)
+                    st = ev.status()
+                    ev.step_end([1.0] * 3, [st[s].time + st[s].dt for s in range(3)],
+                                [st[s].tau + st[s].dt for s in range(3)], [0.0] * 3)
+                else:
+                    ev.update()
+                rows.append([(r.dt, r.time, r.max_phi, r.alias_mass, r.active, r.aliased, r.n_steps) for r in ev.status()])
+            psi = [ev.get_psi(s) for s in range(3)]
+            psik = ev.get_psik(2)
+            ev.calculate_potential(0, 2)
+            phi = [ev.get_potential(s) for s in range(2)]
+        return rows, psi, psik, phi
+    finally:
+        os.environ.pop("MSM_TWO_PASS", None)
+
+
+@pytest.mark.parametrize("cosmology", [None, COSMO], ids=["static", "expanding"])
+def test_two_pass_engine_matches_three_pass_512_f32(cosmology):
+    """The single-precision 512^3 tiling (two passes per transform) against the generic engine (three passes), which the
+    oracle tests pin at every size: same steps and flags, fields equal to single-precision rounding."""
+    r3, psi3, psik3, phi3 = _run_512(0, cosmology)
+    r2, psi2, psik2, phi2 = _run_512(2, cosmology)
+    for a, b in zip(r3, r2):
+        for x, y in zip(a, b):
+            assert x[4:] == y[4:]
+            assert abs(x[0] / y[0] - 1) < 2e-5 and abs(x[1] / y[1] - 1) < 2e-5
+            assert abs(x[2] / y[2] - 1) < 5e-3          # max|phi| of a nearly uniform density is ill-conditioned
+    for s in range(3):
+        assert rel_err(psi2[s], psi3[s]) < 2e-5, s
+    assert rel_err(psik2, psik3) < 2e-5
+    for s in range(2):
+        assert rel_err(phi2[s], phi3[s]) < 1e-2, s
