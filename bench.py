@@ -76,7 +76,7 @@ KINDS_TWO_PASS = {
 
 # pass kind -> kernel name in the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
 # command at 32 streams per launch, corrected as profiles/summarize_pmc.py documents)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v7_pmc_traffic_32streams.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic_32streams.json")
 PMC_KERNEL = {"psi_inv_z": "k_psi_rt<0>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
               "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_rt<1>", "phi_inv_x": "k_phi_max3"}
 

@@ -50,3 +50,20 @@ def test_pmass_hbar_resolution():
     assert hb == 0.05 and pm == 1.757e-90 / 0.05
     pm, hb = msm_amd.determine_pmass_hbar_(1.0, particle_mass=2.0)
     assert pm == 2.0 and hb == 1.757e-90 / 2.0
+
+
+def test_rust_binding_lists_the_same_symbols():
+    # bindings/msm_hip.rs (source only: no Rust toolchain in the build image) declares exactly the header's entry points
+    text = open(os.path.join(ROOT, "bindings", "msm_hip.rs")).read()
+    block = text[text.index('extern "C" {'):text.index("\n}\n", text.index('extern "C" {'))]
+    rust = sorted(set(re.findall(r"pub fn (msm_[a-z_0-9]+)\s*\(", block)))
+    assert rust == _declared()
+    # the two repr(C) structs carry the header's fields in order
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "msm.h")).read(), flags=re.S)
+    for c_name, rs_name in (("msm_config", "MsmConfig"), ("msm_stream_status", "MsmStreamStatus")):
+        c_body = hdr[hdr.index("typedef struct " + c_name):hdr.index("} " + c_name)]
+        c_fields = re.findall(r"\b([a-z_0-9]+)\s*;", c_body)
+        rs_body = text[text.index("pub struct " + rs_name):]
+        rs_body = rs_body[:rs_body.index("}")]
+        rs_fields = re.findall(r"pub ([a-z_0-9]+):", rs_body)
+        assert rs_fields == c_fields, (c_name, rs_fields, c_fields)
