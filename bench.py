@@ -25,6 +25,7 @@ Without a launcher (`WORLD_SIZE` unset) `--gpus N` with N > 1 starts its own N r
 in this process has touched a GPU.
 """
 import argparse
+import datetime
 import json
 import os
 import socket
@@ -162,17 +163,22 @@ def main():
     N = args.size
     n3 = N ** 3
 
-    dist = torch = None
+    store = None
     use_dist = world > 1 or force_dist
     if use_dist:
-        # torch.distributed (gloo, CPU) is the launcher-side plumbing: it hands the communicator id around and agrees on
-        # the clock.  The density grids themselves go through the library's own RCCL communicator (msm_comm_init).
+        # The launcher's key-value store (torch.distributed's TCPStore on MASTER_ADDR:MASTER_PORT) only hands the
+        # communicator id from rank 0 to the others.  Everything else -- the density grids, the barriers around the
+        # timed region, the maximum over the ranks' clocks -- goes through the library's own RCCL communicator.
         import torch            # before the first Evolver: libmsm_hip.so then binds to the HIP runtime torch loaded
-        import torch.distributed as dist
+        from torch.distributed import TCPStore
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: this node shows {torch.cuda.device_count()} GPU(s), --gpus {args.gpus} needs "
                              f"one per rank")
-        dist.init_process_group("gloo")
+        # under torchrun the agent hosts the store and every worker is a client; self-launched, rank 0 hosts it
+        agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world,
+                         is_master=(rank == 0 and not agent_store), timeout=datetime.timedelta(seconds=300),
+                         wait_for_workers=False)
 
     # block partition of the seed list 1..streams (simulator/src/utils/io.rs:183-213 order)
     per = (args.streams + world - 1) // world
@@ -181,9 +187,11 @@ def main():
 
     ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank, **PLANE)
     if use_dist:
-        box = [msm_amd.Evolver.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ev.comm_init(box[0], rank, world)                       # RCCL over xGMI, one rank per GPU
+        key = "msm_bench_comm_id/" + os.environ.get("TORCHELASTIC_RUN_ID", "self") + "/" + \
+              os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        if rank == 0:
+            store.set(key, msm_amd.Evolver.comm_unique_id())
+        ev.comm_init(bytes(store.get(key)), rank, world)        # RCCL over xGMI, one rank per GPU
         ev.mean_density_begin(args.streams)                     # every step now all-reduces sum_s |psi_s|^2
     psi0 = plane_wave_psi(N)
     ev.set_psi(0, psi0)
@@ -205,7 +213,7 @@ def main():
         if use_dist:
             if taken[0]:
                 ev.mean_density(to_host=False)                  # the last step's all-reduce has finished
-            dist.barrier()
+            ev.comm_allreduce([0.0])                            # barrier over the ranks
 
     for i in range(args.warmup):
         one_step(i)
@@ -225,9 +233,7 @@ def main():
     aliased = sum(s.aliased for s in st)
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = ev.comm_allreduce([elapsed], msm_amd.Evolver.COMM_MAX)[0]     # the slowest rank's clock
 
     if rank == 0:
         if steps_done != args.steps or aliased:
@@ -280,8 +286,6 @@ def main():
         print(json.dumps(out), flush=True)
 
     ev.close()
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
