@@ -17,7 +17,7 @@
 // --wave STREAMS: at most that many streams share the device at a time; the rest follow in further waves (the
 //   reference runs them one by one anyway).  Without it the driver starts with all of them and halves the wave
 //   whenever the device reports that it is out of memory.
-// --comm-file PATH (with --world W > 1): the W processes also join one RCCL communicator -- rank 0 publishes the
+// --comm-file PATH: the W processes also join one RCCL communicator (W = 1 is allowed: a communicator of one) -- rank 0 publishes the
 //   128-byte id in PATH (a name unique to this launch, on a file system all ranks see), the others wait for it.
 //   They then stop together when a stream aliases anywhere, and --synthesize works across the ranks: the
 //   synthesizer's sums are all-reduced per dump index and rank 0 writes the -combined/ products.
@@ -90,7 +90,6 @@ Args parse_args(int argc, char** argv) {
     if (a.toml.empty()) usage("The following required arguments were not provided: --toml <TOML>");
     if (a.world < 1 || a.rank < 0 || a.rank >= a.world) usage("--rank must lie in [0, --world)");
     if (a.world > 1 && a.synthesize && a.comm_file.empty()) usage("--synthesize over several processes needs --comm-file (the ranks' sums are all-reduced)");
-    if (a.world == 1 && !a.comm_file.empty()) usage("--comm-file goes with --world W > 1");
     // a resumed stream has passed dumps whose ensemble sums were never formed in this process
     if (a.resume && a.synthesize) usage("--resume cannot be combined with --synthesize");
     return a;

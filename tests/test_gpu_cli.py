@@ -369,9 +369,34 @@ def test_more_streams_than_the_device_holds_run_in_waves(tmp_path):
     assert "running in waves of" in r.stdout
 
 
-def test_two_ranks_over_rccl_need_two_gpus_but_one_rank_world_works(tmp_path):
-    # --comm-file with --world 2 on a one-GPU box cannot form its communicator; the argument checks around it can run
+def test_communicator_driver_path_with_one_rank(tmp_path):
+    # --comm-file at world size 1 (what a one-GPU box can form): the id file hand-off, the per-iteration flag exchange
+    # and the all-reduced synthesizer run through RCCL and must reproduce the plain run's dumps and products exactly
     cfg = dict(TOPHAT, sampling=dict(seeds="1 to 2", scheme="Husimi"))
-    run_cli(tmp_path, cfg, "--comm-file", str(tmp_path / "id"), expect=2)                       # needs --world > 1
+    plain, comm = tmp_path / "plain", tmp_path / "comm"
+    plain.mkdir(); comm.mkdir()
+    run_cli(plain, cfg, "--synthesize")
+    run_cli(comm, cfg, "--synthesize", "--comm-file", str(comm / "id"))
+    assert not (comm / "id").exists()                       # spent once every rank has joined
+    for n in ["spherical-tophat-stream00001", "spherical-tophat-stream00002", "spherical-tophat"]:
+        for k in range(6):
+            assert np.array_equal(load_dump(comm, n, k), load_dump(plain, n, k)), (n, k)
+    for k in range(6):
+        for field in ("psi", "psi2", "psik", "psik2"):
+            assert np.array_equal(load_dump(comm, "spherical-tophat-combined", k, field),
+                                  load_dump(plain, "spherical-tophat-combined", k, field)), (k, field)
+    with open(comm / "sim-data" / "spherical-tophat-combined" / "Qx_real", "rb") as f, \
+         open(plain / "sim-data" / "spherical-tophat-combined" / "Qx_real", "rb") as g:
+        assert np.array_equal(np.load(f), np.load(g))
+    # aliasing with a communicator: every rank (here: the one) leaves through the collective exit, status 101
+    N = 8
+    idx = np.indices((N, N, N)).sum(axis=0)
+    psi = o.normalize(((-1.0) ** idx).astype(np.complex128), 30.0 / N, 3)
+    np.savez(tmp_path / "nyq.npz", real=psi.real, imag=psi.imag)
+    bad = dict(TOPHAT, size=N, ics=dict(type="UserSpecified", path=str(tmp_path / "nyq.npz")),
+               sampling=dict(seeds="1", scheme="Husimi"))
+    r = run_cli(tmp_path, bad, "--comm-file", str(tmp_path / "id2"), expect=101)
+    assert "simulation aliased" in r.stderr
+    # argument checks
     run_cli(tmp_path, cfg, "--synthesize", "--rank", "0", "--world", "2", expect=2)             # needs --comm-file
     run_cli(tmp_path, cfg, "--resume", "--synthesize", expect=2)
