@@ -310,15 +310,17 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
     std::vector<std::pair<double, double>> qx(toml.num_data_dumps + 1, {0.0, 0.0});
     std::vector<char> qx_done(toml.num_data_dumps + 1, 0);
     int synth_next = 0;
+    // seed streams over all ranks: without any there is nothing to synthesize (a TOML without [sampling])
+    const bool synth_on = args.synthesize && agree((double)n_seed_streams, 0) > 0.5;
     const std::string combined = std::string(SIM_DATA_FOLDER) + "/" + toml.sim_name + "-combined";
     auto synthesize = [&](int s, int k) {
-        if (!args.synthesize || s >= n_seed_streams || k < 0 || k > (int)toml.num_data_dumps) return;
+        if (!synth_on || s >= n_seed_streams || k < 0 || k > (int)toml.num_data_dumps) return;
         check(ctx, msm_synth_accumulate(ctx, s, k), "msm_synth_accumulate");
         ++synth_count[k];
     };
     // collective when there is a communicator: every rank calls it once per loop iteration
     auto flush_synth = [&]() {
-        if (!args.synthesize || n_seed_streams + (comm ? 1 : 0) <= 0) return;
+        if (!synth_on) return;
         for (; synth_next <= (int)toml.num_data_dumps; ++synth_next) {
             const int k = synth_next;
             if (agree(synth_count[k] == n_seed_streams ? 1.0 : 0.0, 3) < 0.5) break;
@@ -471,7 +473,7 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
         prev = st;
         flush_synth();
     }
-    if (args.synthesize && lead && n_seed_streams > 0) {
+    if (synth_on && lead) {
         // Qx time series over the dumps (post_combine, synthesizer/src/lib.rs:351-609), shape (n_dumps + 1, 1, 1, 1)
         std::vector<double> re, im;
         for (size_t k = 0; k < qx.size(); ++k)

@@ -400,3 +400,27 @@ def test_communicator_driver_path_with_one_rank(tmp_path):
     # argument checks
     run_cli(tmp_path, cfg, "--synthesize", "--rank", "0", "--world", "2", expect=2)             # needs --comm-file
     run_cli(tmp_path, cfg, "--resume", "--synthesize", expect=2)
+
+
+def test_single_precision_expanding_run(tmp_path):
+    # --precision f32 --expanding: the mode of the largest benchmark configuration through the process surface, against
+    # the oracle run in single precision; dumps are then <f4 planes (utils/io.rs:63-68 with T = f32)
+    cfg = dict(TOPHAT, sim_name="f32cosmo", size=32, final_sim_time=0.6, num_data_dumps=3, cfl=0.05,
+               sampling=dict(seeds="3", scheme="Husimi"),
+               cosmology=dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01))
+    run_cli(tmp_path, cfg, "--expanding", "--precision", "f32")
+    sims = []
+    for params in o.simulation_iter(cfg, expanding=True, dtype=np.float32):
+        sim = o.SimulationObject(params)
+        sim.dump()
+        while sim.not_finished():
+            sim.update()
+        sims.append(sim)
+    assert [s.parameters.sim_name for s in sims] == ["f32cosmo-stream00003", "f32cosmo"]
+    for sim in sims:
+        assert len(sim.dumps) == 4 and sim.parameters.n_steps >= 6
+        for k, psi in sim.dumps:
+            base = tmp_path / "sim-data" / sim.parameters.sim_name / f"psi_{k:05d}"
+            re, im = np.load(open(str(base) + "_real", "rb")), np.load(open(str(base) + "_imag", "rb"))
+            assert re.dtype == np.float32 and re.shape == (32, 32, 32, 1)
+            assert rel((re + 1j * im)[..., 0], psi) < 2e-4, (sim.parameters.sim_name, k)
