@@ -300,6 +300,7 @@ __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* __restri
 #include "kernels_generic.inc"
 #include "kernels_two_pass.inc"
 #include "kernels_two_pass_512.inc"
+#include "kernels_two_pass_128.inc"
 #include "kernels_scalar.inc"
 #include "kernels_unfused.inc"
 
@@ -498,6 +499,7 @@ class Engine final : public IEngine {
     template <int SGN> void launch_any(int ax, const PsiArgs& a, int nblk_y, int kind);
     bool two_pass_ = false;  // every 3-D transform in two passes (N = 256; 512 in single precision); P_ then holds S = pass A of psi between steps
     bool tq_ = false;        // two_pass_ with the 512^3 tiling (kernels_two_pass_512.inc)
+    bool ts_ = false;        // two_pass_ with the 128^3 tiling (kernels_two_pass_128.inc)
     int tp_a_tiles_ = 0, tp_b_blocks_ = 0;   // workgroups per grid of the pass-A / pass-B kernels
     // With S = A[psi] as the state: psi = A^-1[S] / N_A and S' = B^-1[D B[S]] / N_B, where N_A, N_B are the numbers of
     // points the two passes transform over (N_A N_B = N^3; both equal N^{3/2} at 256^3, 16384 and 8192 at 512^3);
@@ -648,7 +650,7 @@ int Engine::init(std::string& err) {
     batch_ = cfg_.batch_streams > 0 ? cfg_.batch_streams : 32;
     if (batch_ < ns_ && (batch_ & 1)) batch_ += 1;
     if (batch_ > ns_) batch_ = ns_;
-    if ((N_ == tp::N || N_ == 512) && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
+    if ((N_ == tp::N || N_ == 512 || N_ == ts::N) && dims_ == 3 && batch_ > tp::MAX_BATCH) batch_ = tp::MAX_BATCH;
     if (batch_ > GENERIC_MAX_BATCH) batch_ = GENERIC_MAX_BATCH;
 
     // ---- scalars in the reference's arithmetic (SimulationParameters::new, :243-274)
@@ -712,10 +714,13 @@ int Engine::init(std::string& err) {
     two_pass_ = two_pass_ || tq_;
     static_assert(tq::MAX_BATCH == tp::MAX_BATCH, "one clamp serves both tilings");
 #endif
-    tp_a_tiles_ = tq_ ? 4096 : tp::A_TILES;
-    tp_b_blocks_ = tq_ ? 4096 : tp::B_BLOCKS;
-    tp_scale_a_ = tq_ ? (real)(1.0 / 16384.0) : c_.unit_scale;
-    tp_scale_b_ = tq_ ? (real)(1.0 / 8192.0) : c_.unit_scale;
+    ts_ = N_ == ts::N && dims_ == 3 && !(tp_env && atoi(tp_env) == 0);
+    two_pass_ = two_pass_ || ts_;
+    static_assert(ts::MAX_BATCH == tp::MAX_BATCH, "one clamp serves all tilings");
+    tp_a_tiles_ = tq_ ? 4096 : ts_ ? ts::A_TILES : tp::A_TILES;
+    tp_b_blocks_ = tq_ ? 4096 : ts_ ? ts::B_BLOCKS : tp::B_BLOCKS;
+    tp_scale_a_ = tq_ ? (real)(1.0 / 16384.0) : ts_ ? (real)(1.0 / 2048.0) : c_.unit_scale;
+    tp_scale_b_ = tq_ ? (real)(1.0 / 8192.0) : ts_ ? (real)(1.0 / 1024.0) : c_.unit_scale;
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     ntiles_ = pw_blocks_;
     if (!anyn_) dispatch_n(N_, [&](auto nc) {
@@ -963,7 +968,15 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
             });
         } else
 #endif
-        {
+        if (ts_) {
+            timed(PK_POISSON_Z, [&] { ks_poisson_b<<<dim3(ts::B_BLOCKS, (unsigned)pairs), dim3(ts::THREADS), 0, stream_>>>(p); });
+            const dim3 grid(ts::A_TILES, (unsigned)pairs), block(ts::THREADS);
+            if (with_x) timed(PK_PHI_X, [&] {
+                if (store_phi && track_max) ks_phi_out<1, 1><<<grid, block, 0, stream_>>>(p);
+                else if (store_phi) ks_phi_out<1, 0><<<grid, block, 0, stream_>>>(p);
+                else ks_phi_out<0, 1><<<grid, block, 0, stream_>>>(p);
+            });
+        } else {
             timed(PK_POISSON_Z, [&] { k_poisson_b<<<dim3(tp::B_BLOCKS, (unsigned)pairs), dim3(tp::B_THREADS), 0, stream_>>>(p); });
             const dim3 grid(tp::A_TILES, (unsigned)pairs), block(tp::A_THREADS);
             if (with_x) timed(PK_PHI_X, [&] {
@@ -1006,7 +1019,8 @@ void Engine::poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool st
         if (tq_) timed(PK_RHO_X, [&] { k5_rho_pass<<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tq::THREADS), 0, stream_>>>(p); });
         else
 #endif
-        timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
+        if (ts_) timed(PK_RHO_X, [&] { ks_rho_pass<<<dim3(ts::A_TILES, (unsigned)((nb + 1) / 2)), dim3(ts::THREADS), 0, stream_>>>(p); });
+        else timed(PK_RHO_X, [&] { k_rho_pass2<<<dim3(tp::A_TILES, (unsigned)((nb + 1) / 2)), dim3(tp::A_THREADS), 0, stream_>>>(p); });
     } else dispatch_n(N_, [&](auto nc) {
         constexpr int N = decltype(nc)::value;
         using G0 = Geom<N, 0>;
@@ -1032,6 +1046,14 @@ void Engine::psi_rt(const cplx* src, cplx* dst, bool alias, int s0, int n, const
         return;
     }
 #endif
+    if (ts_) {
+        const dim3 grid(ts::B_BLOCKS, (unsigned)n), block(ts::THREADS);
+        timed(kind, [&] {
+            if (alias) ks_psi_rt<1><<<grid, block, 0, stream_>>>(b);
+            else ks_psi_rt<0><<<grid, block, 0, stream_>>>(b);
+        });
+        return;
+    }
     const dim3 grid(tp::B_BLOCKS, (unsigned)n), block(tp::B_THREADS);
     timed(kind, [&] {
         if (alias) k_psi_rt<1><<<grid, block, 0, stream_>>>(b);
@@ -1045,6 +1067,7 @@ void Engine::psi_b_fwd(const cplx* src, cplx* dst, int s0, int n) {
 #ifdef MSM_TQ
     if (tq_) { timed(PK_PLAIN, [&] { k5_psi_b_fwd<<<dim3(tq::B_BLOCKS, (unsigned)n), dim3(tq::THREADS), 0, stream_>>>(b); }); return; }
 #endif
+    if (ts_) { timed(PK_PLAIN, [&] { ks_psi_b_fwd<<<dim3(ts::B_BLOCKS, (unsigned)n), dim3(ts::THREADS), 0, stream_>>>(b); }); return; }
     timed(PK_PLAIN, [&] { k_psi_b_fwd<<<dim3(tp::B_BLOCKS, (unsigned)n), dim3(tp::B_THREADS), 0, stream_>>>(b); });
 }
 
@@ -1062,6 +1085,14 @@ void Engine::psi_a(int sgn, const cplx* src, bool src_local, cplx* dst, bool dst
         return;
     }
 #endif
+    if (ts_) {
+        const dim3 grid(ts::A_TILES, (unsigned)n), block(ts::THREADS);
+        timed(PK_PLAIN, [&] {
+            if (sgn < 0) ks_psi_a<-1><<<grid, block, 0, stream_>>>(a);
+            else ks_psi_a<+1><<<grid, block, 0, stream_>>>(a);
+        });
+        return;
+    }
     {
         const dim3 grid(tp::A_TILES, (unsigned)n), block(tp::A_THREADS);
         timed(PK_PLAIN, [&] {
@@ -1154,7 +1185,8 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
 
     if (lowdim_) { lowdim_step_back(s0, nb, nt, ntau, stau); return; }
     if (two_pass_) {
-        const dim3 gridA(tp_a_tiles_), gridAp(tp_a_tiles_, (unsigned)((nb + 1) / 2)), blockA(tq_ ? 512 : tp::A_THREADS);
+        const dim3 gridA(tp_a_tiles_), gridAp(tp_a_tiles_, (unsigned)((nb + 1) / 2)), blockA(512);
+        static_assert(tp::A_THREADS == 512 && ts::THREADS == 512, "all tilings launch their A kernels with 512 threads");
         // one launch of the fused inverse-x / density / Poisson-forward pass, and of the kick pass, in either tiling
         auto invx_rho = [&](bool dens) {
             timed(PK_INVX_RHO, [&] {
@@ -1165,6 +1197,11 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
                     return;
                 }
 #endif
+                if (ts_) {
+                    if (dens) ks_invx_rho<1><<<gridA, blockA, 0, stream_>>>(p);
+                    else ks_invx_rho<0><<<gridA, blockA, 0, stream_>>>(p);
+                    return;
+                }
                 if (dens) k_invx_rho3<1><<<gridA, blockA, 0, stream_>>>(p);
                 else k_invx_rho3<0><<<gridA, blockA, 0, stream_>>>(p);
             });
@@ -1174,6 +1211,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
 #ifdef MSM_TQ
                 if (tq_) { k5_kick<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); return; }
 #endif
+                if (ts_) { ks_kick<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); return; }
                 k_kick3<<<gridAp, blockA, 0, stream_>>>(p, st_.kick);
             });
         };
@@ -1390,6 +1428,7 @@ int Engine::potential(int first, int count, std::string& err) {
 #ifdef MSM_TQ
                 if (tq_) { k5_invx_rho<0><<<dim3(tq::A_TILES), dim3(tq::THREADS), 0, stream_>>>(p); return; }
 #endif
+                if (ts_) { ks_invx_rho<0><<<dim3(ts::A_TILES), dim3(ts::THREADS), 0, stream_>>>(p); return; }
                 k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
             });
         }

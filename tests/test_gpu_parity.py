@@ -372,14 +372,14 @@ def test_steps_and_potential_256_vs_cpu_port():
         sim.close()
 
 
-def _run_mode_256(mode, cosmology=None, precision="f64"):
+def _run_mode_256(mode, cosmology=None, precision="f64", N=256):
     """Five streams in sub-batches of four (one unpaired), stream 1 carrying grid-scale noise so that
     it aliases on the first step and sits out the rest; returns status rows and fields."""
-    N = 256
     os.environ["MSM_TWO_PASS"] = str(mode)
     try:
         base = dict(TOPHAT, cfl=0.05, alias_threshold=1e-4, k2_cutoff=0.5)
         with Evolver(size=N, n_streams=5, batch_streams=4, cosmology=cosmology, precision=precision, **base) as ev:
+            assert ev.derived()["transform_passes_mode"] == float(mode)
             for s in range(5):
                 psi = rand_psi(N, 20 + s) * (0.5 if s == 1 else 1e-3) + 1.0
                 ev.set_psi(s, o.normalize(psi, 30.0 / N, 3).astype(ev.cplx))
@@ -402,15 +402,16 @@ def _run_mode_256(mode, cosmology=None, precision="f64"):
         os.environ.pop("MSM_TWO_PASS", None)
 
 
+@pytest.mark.parametrize("N", [256, 128])
 @pytest.mark.parametrize("cosmology", [None, dict(omega_matter_now=1.0, omega_radiation_now=0.0, h=0.7, z0=9.0, max_dloga=0.01)],
                          ids=["static", "expanding"])
 @pytest.mark.parametrize("precision,tol,stol", [("f64", 1e-11, 1e-11), ("f32", 2e-4, 2e-5)])
-def test_two_pass_engine_matches_three_pass_256(cosmology, precision, tol, stol):
-    """The 256^3 two-pass engine (blocked work-array layouts, state kept as the pass-A image of psi) against the
-    plain three-passes-per-transform engine that the small-N oracle tests pin: same steps, same
+def test_two_pass_engine_matches_three_pass_256(cosmology, precision, tol, stol, N):
+    """The two-pass engines (256^3 and 128^3: blocked work-array layouts, state kept as the pass-A image of psi) against
+    the plain three-passes-per-transform engine that the small-N oracle tests pin: same steps, same
     activity flags, fields equal to rounding -- with an unpaired stream and a stream that drops out."""
-    r3, psi3, psik3, phi3 = _run_mode_256(0, cosmology, precision)
-    r2, psi2, psik2, phi2 = _run_mode_256(2, cosmology, precision)
+    r3, psi3, psik3, phi3 = _run_mode_256(0, cosmology, precision, N)
+    r2, psi2, psik2, phi2 = _run_mode_256(2, cosmology, precision, N)
     assert [row[1][4] for row in r3] == [0, 0, 0] and r3[0][1][5] == 1       # stream 1 aliased at step 1
     for a, b in zip(r3, r2):
         for x, y in zip(a, b):

@@ -70,10 +70,11 @@ def test_expanding_golden_steps(name, precision, tol, dtol, golden_dir):
         assert ev.status()[0].current_dumps == 3 and ev.status()[0].active == 0
 
 
-@pytest.mark.parametrize("N,precision,tol,dtol", [(32, "f32", 2e-4, 2e-6), (32, "f64", 1e-11, 1e-12), (64, "f32", 2e-4, 2e-6)])
+@pytest.mark.parametrize("N,precision,tol,dtol", [(32, "f32", 2e-4, 2e-6), (32, "f64", 1e-11, 1e-12), (64, "f32", 2e-4, 2e-6),
+                                                  (128, "f64", 1e-11, 1e-12), (128, "f32", 2e-4, 2e-6)])
 def test_expanding_streams_vs_oracle(N, precision, tol, dtol):
-    """Three streams (mean field + two Husimi seeds, one Poisson pair and one unpaired) in an expanding box on the
-    generic engine, every step against the oracle in the same precision."""
+    """Three streams (mean field + two Husimi seeds, one Poisson pair and one unpaired) in an expanding box, every step
+    against the oracle in the same precision: the generic engine at N = 32, 64, the 128^3 two-pass tiling at N = 128."""
     dtype = np.float32 if precision == "f32" else np.float64
     sims = oracle_sims(COSMO_BASE, N, 3, dtype, expanding=True)
     with Evolver(size=N, n_streams=3, precision=precision, **evolver_kwargs(COSMO_BASE, True)) as ev:
