@@ -440,6 +440,9 @@ class Engine final : public IEngine {
     void lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act);
     void lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
     PoisArgs pois_args(int s0, int nb, const int* act) const;
+#ifdef MSM_TQ
+    void tq_rho_from_state(const PoisArgs& p, int nb, bool dens);
+#endif
     // W passes after the fused/rho x pass; with_x = false leaves F_y,z-inverted W for a fused consumer
     void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
     // act = all_active_ solves for finished streams too (standalone msm_potential)
@@ -719,8 +722,8 @@ int Engine::init(std::string& err) {
     static_assert(ts::MAX_BATCH == tp::MAX_BATCH, "one clamp serves all tilings");
     tp_a_tiles_ = tq_ ? 4096 : ts_ ? ts::A_TILES : tp::A_TILES;
     tp_b_blocks_ = tq_ ? 4096 : ts_ ? ts::B_BLOCKS : tp::B_BLOCKS;
-    tp_scale_a_ = tq_ ? (real)(1.0 / 16384.0) : ts_ ? (real)(1.0 / 2048.0) : c_.unit_scale;
-    tp_scale_b_ = tq_ ? (real)(1.0 / 8192.0) : ts_ ? (real)(1.0 / 1024.0) : c_.unit_scale;
+    tp_scale_a_ = tq_ ? (real)(1.0 / 8192.0) : ts_ ? (real)(1.0 / 2048.0) : c_.unit_scale;
+    tp_scale_b_ = tq_ ? (real)(1.0 / 16384.0) : ts_ ? (real)(1.0 / 1024.0) : c_.unit_scale;
     // per-workgroup partials: the x-pass and z-pass tilings may differ
     ntiles_ = pw_blocks_;
     if (!anyn_) dispatch_n(N_, [&](auto nc) {
@@ -949,6 +952,17 @@ PoisArgs Engine::pois_args(int s0, int nb, const int* act) const {
     p.partial = partial_; p.ntiles = ntiles_; p.dens = nullptr;
     return p;
 }
+
+#ifdef MSM_TQ
+// 512^3 tiling: pass A^-1 of the batch's states -> rho of every stream as a real grid (in the potential array) -> pass A
+// of rho_a + i rho_b into W; optionally the ensemble density of the streams in p.active.
+void Engine::tq_rho_from_state(const PoisArgs& p, int nb, bool dens) {
+    const dim3 block(tq::THREADS);
+    k5_inv_rho<<<dim3(tq::A_TILES, (unsigned)nb), block, 0, stream_>>>(p);
+    if (dens) k5_dens_from_rho<<<2048, 256, 0, stream_>>>(PHI_, n3_, nb, p.active, p.s0, 1.0 / (double)c_.mass_factor, p.dens);
+    k5_rho_fwd<<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), block, 0, stream_>>>(p);
+}
+#endif
 
 // y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
 // (two-pass layout: W holds T and one pass-B kernel replaces the three middle passes)
@@ -1191,11 +1205,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         auto invx_rho = [&](bool dens) {
             timed(PK_INVX_RHO, [&] {
 #ifdef MSM_TQ
-                if (tq_) {
-                    if (dens) k5_invx_rho<1><<<gridA, blockA, 0, stream_>>>(p);
-                    else k5_invx_rho<0><<<gridA, blockA, 0, stream_>>>(p);
-                    return;
-                }
+                if (tq_) { tq_rho_from_state(p, nb, dens); return; }
 #endif
                 if (ts_) {
                     if (dens) ks_invx_rho<1><<<gridA, blockA, 0, stream_>>>(p);
@@ -1209,7 +1219,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         auto kick = [&] {
             timed(PK_FWD_X, [&] {
 #ifdef MSM_TQ
-                if (tq_) { k5_kick<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); return; }
+                if (tq_) { k5_kick<<<dim3(tq::A_TILES, (unsigned)nb), blockA, 0, stream_>>>(p, st_.kick); return; }
 #endif
                 if (ts_) { ks_kick<<<gridAp, blockA, 0, stream_>>>(p, st_.kick); return; }
                 k_kick3<<<gridAp, blockA, 0, stream_>>>(p, st_.kick);
@@ -1224,7 +1234,8 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         // pass A^-1 fused with rho and the Poisson pass A
         psi_rt(S, S, false, s0, nb, st_.active, PK_INV_Z);
         invx_rho(false);
-        poisson_tail(s0, nb, false, false, false);
+        // (the 512^3 tiling hands phi to the kick as a real grid: its Poisson solve ends with the A^-1 pass)
+        poisson_tail(s0, nb, tq_, false, tq_);
         // kick between the two A passes; the second round trip applies the second drift, sums the aliased mass
         // and leaves the new state
         kick();
@@ -1237,6 +1248,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         p.active = st_.stepped;
         invx_rho(step_dens_ != nullptr);
         poisson_tail(s0, nb, false, true, true, st_.stepped);
+        if (tq_) phi_nb_ = 0;   // the rho grids went through the potential array
         return;
     }
 
@@ -1426,7 +1438,7 @@ int Engine::potential(int first, int count, std::string& err) {
             p.scale = tp_scale_a_;
             timed(PK_INVX_RHO, [&] {
 #ifdef MSM_TQ
-                if (tq_) { k5_invx_rho<0><<<dim3(tq::A_TILES), dim3(tq::THREADS), 0, stream_>>>(p); return; }
+                if (tq_) { tq_rho_from_state(p, count, false); return; }
 #endif
                 if (ts_) { ks_invx_rho<0><<<dim3(ts::A_TILES), dim3(ts::THREADS), 0, stream_>>>(p); return; }
                 k_invx_rho3<0><<<dim3(tp::A_TILES), dim3(tp::A_THREADS), 0, stream_>>>(p);
