@@ -99,10 +99,10 @@ const char* msm_last_error(const msm_ctx* ctx);   /* ctx may be NULL: last creat
  * (simulation_object.rs:325-363).  out = {dx, dk, k2_max, hbar_, n_tot,
  * kinetic_dt, comoving_boxsize(or 0), transform mode}; the last entry is
  * diagnostic: 0 = three passes per 3-D transform, 2 = a two-pass engine
- * (128^3 and 256^3; the state is then held as a half-transformed image of
- * psi internally, downloads are unaffected; MSM_TWO_PASS=0 in the
- * environment selects the generic engine, MSM_TWO_PASS=2 also the
- * experimental single-precision 512^3 tiling). */
+ * (128^3 and 256^3 in both precisions, 512^3 in single precision; the
+ * state is then held as a half-transformed image of psi internally,
+ * downloads are unaffected; MSM_TWO_PASS=0 in the environment selects the
+ * generic three-pass engine). */
 int32_t msm_get_derived(const msm_ctx* ctx, double out[8]);
 
 /* Initial conditions.

@@ -710,10 +710,9 @@ int Engine::init(std::string& err) {
     const char* tp_env = getenv("MSM_TWO_PASS");
     if (tp_env) two_pass_ = two_pass_ && atoi(tp_env) != 0;   // 0: the generic three-pass engine
 #ifdef MSM_TQ
-    // The single-precision 512^3 tiling is built and parity-tested but not selected by default: its tiles share only
-    // 64-byte blocks, each workgroup touches the two halves of a block tens of microseconds apart, and the step is
-    // slower than with three passes (measurements: tools/bench_c5.py).  MSM_TWO_PASS=2 selects it.
-    tq_ = N_ == tq::N && dims_ == 3 && tp_env && atoi(tp_env) == 2;
+    // The single-precision 512^3 tiling (register-resident tiles, kernels_two_pass_512.inc) is the default for that grid;
+    // MSM_TWO_PASS=0 selects the three-pass engine (measurements of both: tools/bench_c5.py).
+    tq_ = N_ == tq::N && dims_ == 3 && !(tp_env && atoi(tp_env) == 0);
     two_pass_ = two_pass_ || tq_;
     static_assert(tq::MAX_BATCH == tp::MAX_BATCH, "one clamp serves both tilings");
 #endif

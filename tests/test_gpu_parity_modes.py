@@ -187,8 +187,8 @@ def test_two_pass_256_expanding_vs_numpy_oracle(oracle_256_expanding, precision,
 @pytest.mark.parametrize("two_pass", [0, 2], ids=["three-pass", "two-pass"])
 def test_512_f32_expanding_step_vs_oracle(two_pass):
     """One expanding step of one stream at 512^3 in single precision (the per-GPU grid of the largest benchmark
-    configuration) against the oracle run in the same precision, on the generic engine (the default at this size) and
-    on the two-pass tiling (MSM_TWO_PASS=2)."""
+    configuration) against the oracle run in the same precision, on the generic three-pass engine (MSM_TWO_PASS=0) and
+    on the two-pass tiling (the default at this size in single precision)."""
     N = 512
     o.FFT_WORKERS = 8
     os.environ["MSM_TWO_PASS"] = str(two_pass)
