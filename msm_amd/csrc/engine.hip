@@ -444,7 +444,8 @@ class Engine final : public IEngine {
     void tq_rho_from_state(const PoisArgs& p, int nb, bool dens);
 #endif
     // W passes after the fused/rho x pass; with_x = false leaves F_y,z-inverted W for a fused consumer
-    void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr);
+    void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr,
+                      bool phi_for_kick = false);
     // act = all_active_ solves for finished streams too (standalone msm_potential)
     void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act);
     // two-pass psi transforms (two_pass_): the kinetic round trip through pass B, psi_k for downloads, and pass A
@@ -965,10 +966,11 @@ void Engine::tq_rho_from_state(const PoisArgs& p, int nb, bool dens) {
 
 // y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
 // (two-pass layout: W holds T and one pass-B kernel replaces the three middle passes)
-void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x, const int* act) {
+void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x, const int* act, bool phi_for_kick) {
     if (!act) act = st_.active;
     const int pairs = (nb + 1) / 2;
-    const PoisArgs p = pois_args(s0, nb, act);
+    PoisArgs p = pois_args(s0, nb, act);
+    p.phi_tiled = phi_for_kick ? 1 : 0;
     if (two_pass_) {
 #ifdef MSM_TQ
         if (tq_) {
@@ -999,7 +1001,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
             });
         }
         if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp_a_tiles_, s0, act);
-        if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
+        if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = phi_for_kick ? 0 : nb; }   // (tile order is not for downloads)
         return;
     }
     PsiArgs a{};
@@ -1234,7 +1236,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         psi_rt(S, S, false, s0, nb, st_.active, PK_INV_Z);
         invx_rho(false);
         // (the 512^3 tiling hands phi to the kick as a real grid: its Poisson solve ends with the A^-1 pass)
-        poisson_tail(s0, nb, tq_, false, tq_);
+        poisson_tail(s0, nb, tq_, false, tq_, nullptr, tq_);
         // kick between the two A passes; the second round trip applies the second drift, sums the aliased mass
         // and leaves the new state
         kick();
