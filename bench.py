@@ -75,20 +75,23 @@ KINDS_TWO_PASS = {
 }
 
 
-# pass kind -> kernel name in the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-# command at 32 streams per launch, corrected as profiles/summarize_pmc.py documents)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic_32streams.json")
+# pass kind -> kernel name in the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+# command at 32 and at 128 streams per launch, corrected as profiles/summarize_pmc.py documents)
+PMC_SUMMARY = {32: os.path.join(ROOT, "profiles", "r02_pmc_traffic_32streams.json"),
+               128: os.path.join(ROOT, "profiles", "r02_pmc_traffic_128streams.json")}
 PMC_KERNEL = {"psi_inv_z": "k_psi_rt<0>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
               "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_rt<1>", "phi_inv_x": "k_phi_max3"}
 
 
 def measured_traffic(kind, two_pass, cells_per_launch, n3):
     """HBM bytes per launch of the dominant kernel from the PMC counters, when the committed summary covers this
-    launch shape (two-pass engine, 32 x 256^3 cells per launch); None otherwise."""
-    if not two_pass or cells_per_launch != 32 * n3 or n3 != 256 ** 3 or kind not in PMC_KERNEL:
+    launch shape (two-pass engine, 32 or 128 x 256^3 cells per launch); None otherwise."""
+    per_launch = cells_per_launch // n3
+    if not two_pass or cells_per_launch != per_launch * n3 or per_launch not in PMC_SUMMARY or n3 != 256 ** 3 \
+            or kind not in PMC_KERNEL:
         return None
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(PMC_SUMMARY[per_launch]) as f:
             return int(json.load(f)[PMC_KERNEL[kind]]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
@@ -148,7 +151,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--streams", type=int, default=256, help="total streams over all GPUs")
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=128, help="streams per kernel launch (sub-batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
