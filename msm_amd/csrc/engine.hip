@@ -954,12 +954,12 @@ PoisArgs Engine::pois_args(int s0, int nb, const int* act) const {
 }
 
 #ifdef MSM_TQ
-// 512^3 tiling: pass A^-1 of the batch's states -> rho of every stream as a real grid (in the potential array) -> pass A
-// of rho_a + i rho_b into W; optionally the ensemble density of the streams in p.active.
+// 512^3 tiling: pass A^-1 of the batch's states -> |psi|^2 of every stream as a real grid (in the potential array) ->
+// pass A of rho_a + i rho_b into W; optionally the ensemble density of the streams in p.active.
 void Engine::tq_rho_from_state(const PoisArgs& p, int nb, bool dens) {
     const dim3 block(tq::THREADS);
     k5_inv_rho<<<dim3(tq::A_TILES, (unsigned)nb), block, 0, stream_>>>(p);
-    if (dens) k5_dens_from_rho<<<2048, 256, 0, stream_>>>(PHI_, n3_, nb, p.active, p.s0, 1.0 / (double)c_.mass_factor, p.dens);
+    if (dens) k5_dens_from_rho<<<2048, 256, 0, stream_>>>(PHI_, n3_, nb, p.active, p.s0, p.dens);
     k5_rho_fwd<<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), block, 0, stream_>>>(p);
 }
 #endif

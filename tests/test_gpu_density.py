@@ -35,7 +35,7 @@ def test_step_density_against_downloads(N, dims, ns, batch, precision):
     base = dict(TOPHAT, final_sim_time=0.02, num_data_dumps=2, cfl=0.5)
     rng = np.random.default_rng(N + dims)
     shape = (N,) * dims
-    # single precision: the 512^3 tiling sums the density from the rho grids it writes (one rounding more than |psi|^2)
+    # single precision: the 512^3 tiling sums the density from the |psi|^2 grids it writes
     tol = 1e-11 if precision == "f64" else 1e-5
     with Evolver(size=N, dims=dims, n_streams=ns, batch_streams=batch, precision=precision, **base) as ev:
         for s in range(ns):
