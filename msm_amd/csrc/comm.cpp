@@ -3,6 +3,8 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <mutex>
 
 namespace msm {
@@ -13,7 +15,13 @@ std::string g_err;
 std::mutex g_mutex;
 
 void* open_rccl(std::string& origin) {
-    // a copy that is already mapped wins (RTLD_NOLOAD); then the loader's search path; then the ROCm tree
+    // MSM_RCCL_LIB names the one library to bind (a site's own build; the tests name a file that does not exist to
+    // take the failure path); otherwise a copy that is already mapped wins (RTLD_NOLOAD), then the loader's search
+    // path, then the ROCm tree
+    if (const char* forced = std::getenv("MSM_RCCL_LIB")) {
+        origin = forced;
+        return dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    }
     static const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* n : names)
         if (void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) { origin = std::string(n) + " (already loaded)"; return h; }
@@ -32,7 +40,8 @@ const Rccl* rccl(std::string& err) {
         g_tried = true;
         void* h = open_rccl(g_rccl.origin);
         if (!h) {
-            g_err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            const char* why = dlerror();      // one call: it hands the message over and clears it
+            g_err = std::string("librccl not found: ") + (why ? why : "dlopen failed");
         } else {
             auto sym = [&](const char* name) -> void* {
                 void* p = dlsym(h, name);

@@ -67,3 +67,25 @@ def test_rust_binding_lists_the_same_symbols():
         rs_body = rs_body[:rs_body.index("}")]
         rs_fields = re.findall(r"pub ([a-z_0-9]+):", rs_body)
         assert rs_fields == c_fields, (c_name, rs_fields, c_fields)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    # the communicator calls bind librccl on first use; when no copy can be opened they must hand back
+    # MSM_ERR_INVALID and a message.  The binding is cached per process, hence the child process.
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import msm_amd\n"
+        "lib = msm_amd.load()\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "for _ in range(2):\n"                       # the second call reads the cached failure
+        "    rc = lib.msm_comm_unique_id(buf)\n"
+        "    msg = lib.msm_last_error(None).decode()\n"
+        "    assert rc == -1 and msg.startswith('librccl not found: ') and len(msg) > 25, (rc, msg)\n"
+        "print('clean:', msg)\n")
+    env = dict(os.environ, MSM_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "clean: librccl not found: /nonexistent/librccl.so.1" in r.stdout
