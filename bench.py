@@ -21,6 +21,15 @@ must write once, per stream-cell (KINDS*: second entry) -- over its measured lau
 PMC counters saw it move.  The whole-step figures `step_frac*` use the reference-level model of 224 B per update
 (7 transforms, one read and one write each); `model224_*` is that model's share attributed to the kernel.
 
+With one GPU the same line also carries `extra_configs`: the other single-GPU configurations of the benchmark list,
+each run after the headline context has been closed, with its own timed steps and HIP-event pass timings --
+  c2_128_1stream / c2_128_64streams   examples/spherical-tophat.toml at size 128, fp64, static box
+  c3_256_64streams                    tomls/planeWave3d_e10_sym.toml at size 256, 64 Wigner streams in sub-batches of 32
+  c5_512_f32_expanding_64streams      examples/spherical-tophat-cosmo.toml at size 512, fp32, expanding box, the 64
+                                      streams one GPU holds of the 512; the scale-factor bookkeeping between
+                                      msm_step_begin and msm_step_end is the native host loop msm-simulator uses
+`--configs headline` leaves them out; `--extra-budget-s` bounds their wall time.
+
 Without a launcher (`WORLD_SIZE` unset) `--gpus N` with N > 1 starts its own N rank processes, before anything
 in this process has touched a GPU.
 """
@@ -31,6 +40,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -39,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import msm_amd  # noqa: E402
+from msm_amd._lib import kernel_source_hash  # noqa: E402
 from msm_amd.ics import plane_wave_psi  # noqa: E402
 from msm_amd.sharding import partition_streams  # noqa: E402
 
@@ -77,24 +88,31 @@ KINDS_TWO_PASS = {
 
 # pass kind -> kernel name in the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
 # command at 32 and at 128 streams per launch, corrected as profiles/summarize_pmc.py documents)
-PMC_SUMMARY = {32: os.path.join(ROOT, "profiles", "r02_pmc_traffic_32streams.json"),
-               128: os.path.join(ROOT, "profiles", "r02_pmc_traffic_128streams.json")}
+PMC_SUMMARY = {32: os.path.join(ROOT, "profiles", "r03_pmc_traffic_32streams.json"),
+               128: os.path.join(ROOT, "profiles", "r03_pmc_traffic_128streams.json")}
 PMC_KERNEL = {"psi_inv_z": "k_psi_rt<0>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
               "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_rt<1>", "phi_inv_x": "k_phi_max3"}
 
 
 def measured_traffic(kind, two_pass, cells_per_launch, n3):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, when the committed summary covers this
-    launch shape (two-pass engine, 32 or 128 x 256^3 cells per launch); None otherwise."""
+    """(HBM bytes per launch of the dominant kernel from the PMC counters, note).  The bytes are reported only when a
+    committed summary covers this launch shape (two-pass engine, 32 or 128 x 256^3 cells per launch) AND was taken
+    from the device sources this run's library was built from (the summary's `_meta.kernel_source_hash`)."""
     per_launch = cells_per_launch // n3
     if not two_pass or cells_per_launch != per_launch * n3 or per_launch not in PMC_SUMMARY or n3 != 256 ** 3 \
             or kind not in PMC_KERNEL:
-        return None
+        return None, "no PMC summary covers this launch shape"
     try:
         with open(PMC_SUMMARY[per_launch]) as f:
-            return int(json.load(f)[PMC_KERNEL[kind]]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+            summary = json.load(f)
+        profiled = summary.get("_meta", {}).get("kernel_source_hash")
+        here = kernel_source_hash()
+        if not profiled or profiled != here:
+            return None, (f"{os.path.basename(PMC_SUMMARY[per_launch])} was taken from other device sources "
+                          f"(hash {str(profiled)[:12]}, this tree {here[:12]}): profile again")
+        return int(summary[PMC_KERNEL[kind]]["hbm_bytes_per_launch"]), os.path.basename(PMC_SUMMARY[per_launch])
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"PMC summary unreadable: {e}"
 
 
 def cpu_baseline(size, seconds_cap=30.0):
@@ -119,6 +137,179 @@ def cpu_baseline(size, seconds_cap=30.0):
                 sample=f"{size}^3 fp64, 1 stream, {steps} timed steps of the C/OpenMP restatement of the "
                        f"reference algorithm (not ArrayFire), {sim.threads} threads",
                 seconds=round(dt, 2))
+
+
+# ---------------------------------------------------------------------------
+# The other single-GPU configurations of the benchmark list, on the same clock
+# ---------------------------------------------------------------------------
+TOPHAT_TOML = """axis_length = 30
+final_sim_time = 40
+cfl = 0.5
+num_data_dumps = 200
+total_mass = 1e11
+hbar_ = 0.05
+sim_name = "{name}"
+k2_cutoff = 0.95
+alias_threshold = 0.02
+dims = 3
+size = {size}
+
+[ics]
+type = "SphericalTophat"
+radius = 5.0
+slope = 50
+delta = 100
+{sampling}{cosmology}"""                 # examples/spherical-tophat.toml and spherical-tophat-cosmo.toml, size overridden
+TOPHAT_COSMOLOGY = """
+[cosmology]
+omega_matter_now = 0.7
+omega_radiation_now = 0.0
+h = 0.7
+z0 = 1.0
+max_dloga = 0.01
+"""
+# bytes one launch of a pass kind reads + writes per stream-cell, by engine (double precision; halve for single):
+#   two-pass tilings of 128^3 and 256^3 = KINDS_TWO_PASS, generic engine = KINDS, and the 512^3 single-precision
+#   tiling, where |psi|^2 and phi cross memory as real grids (given in single-precision bytes)
+KINDS_TILING_512_F32 = {"psi_inv_z": 16.0, "psi_invx_rho": 20.0, "poisson_z": 8.0, "phi_inv_x": 6.0, "psi_fwd_x": 20.0,
+                        "psi_fwdz_invz": 16.0, "rho_fwd_x": 12.0, "plain": 16.0}
+MOVED_512_F32 = 120.0
+
+
+def run_config(name, workload, toml_text, size, streams, batch, precision, expanding, scheme, steps, warmup,
+               psi0=None, params=None):
+    """One configuration from its TOML: context, ICs, `warmup` + `steps` timed updates with the host reading the
+    status after every step (as the reference's loop does), then a second, shorter leg with HIP events around every
+    pass launch for the per-kind times.  Returns the entry of `extra_configs`."""
+    from msm_amd import host as mh
+    from msm_amd.expanding import ExpandingHost
+
+    t_enter = time.perf_counter()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "run.toml")
+        with open(path, "w") as f:
+            f.write(toml_text)
+        t = mh.read_toml(path, expanding)
+        kw = dict(axis_length=t["axis_length"], final_sim_time=t["final_sim_time"], cfl=t["cfl"],
+                  num_data_dumps=t["num_data_dumps"], total_mass=t["total_mass"], k2_cutoff=t["k2_cutoff"],
+                  alias_threshold=t["alias_threshold"], particle_mass=t["resolved_particle_mass"],
+                  hbar_=t["resolved_hbar_"])
+        if params:
+            kw.update(params)
+        ev = msm_amd.Evolver(size=size, n_streams=streams, batch_streams=batch, precision=precision,
+                             cosmology=t["cosmology"] if expanding else None, **kw)
+        if psi0 is None:
+            psi0 = mh.build_ics(path, size, 3, ev.derived()["dx"], precision, expanding)
+    try:
+        ev.set_psi(0, psi0)
+        del psi0
+        for s in range(1, streams):
+            ev.copy_psi(s, 0)
+        if scheme:
+            for s in range(streams):
+                ev.sample(s, scheme, s + 1)          # seeds 1..streams, one per stream
+        xhost = ExpandingHost(t["cosmology"], streams, precision, t["final_sim_time"], t["num_data_dumps"]) if expanding else None
+        state = {"st": ev.status()}
+
+        def one_step():
+            if xhost is None:
+                ev.update()
+                state["st"] = ev.status()           # synchronises: dt, dump flags, activity on the host
+            else:
+                state["st"] = xhost.update(ev, state["st"])
+
+        for _ in range(warmup):
+            one_step()
+        ev.sync()
+        n0 = min(r.n_steps for r in state["st"])
+        ev.timer_start()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        ev.sync()
+        wall = time.perf_counter() - t0
+        ev_ms = ev.timer_stop_ms()
+        st = state["st"]
+        done = min(r.n_steps for r in st) - n0
+        aliased = sum(r.aliased for r in st)
+        if done != steps or aliased:
+            return dict(workload=workload, error=f"{done} of {steps} steps done, {aliased} streams aliased")
+        # second leg: per-kind pass times (event records switch off the graph replay of small grids, hence not in the timed leg)
+        psteps = max(2, min(steps, 10))
+        ev.profile(True)
+        for _ in range(psteps):
+            one_step()
+        prof = {k: v for k, v in ev.profile_report().items() if v[1] > 0}
+        ev.profile(False)
+        st = state["st"]
+        mode = ev.derived()["transform_passes_mode"]
+    finally:
+        ev.close()
+    n3 = size ** 3
+    f = 1.0 if precision == "f64" else 0.5
+    if mode >= 2.0 and size == 512:
+        table, moved_step, engine = KINDS_TILING_512_F32, MOVED_512_F32, "two passes per transform, register-resident 2^15-point tiles"
+    elif mode >= 2.0:
+        table = {k: v[1] * f for k, v in KINDS_TWO_PASS.items()}
+        moved_step, engine = B_MOVED_STEP_TWO_PASS * f, "two passes per transform"
+    else:
+        table = {k: v[1] * f for k, v in KINDS.items()}
+        moved_step, engine = B_MOVED_STEP_GENERIC * f, "three passes per transform"
+    alg_step = B_ALG_STEP * f
+    ups = n3 * streams * steps / wall
+    kind, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
+    cells = n3 * min(batch or streams, streams)
+    k_gbs = table[kind] * cells / (kms / kcnt / 1e3) / 1e9
+    return dict(workload=workload, engine=engine, dtype=precision, streams=streams, batch_streams=min(batch or streams, streams),
+                steps=steps, warmup=warmup, ms_per_step=round(wall / steps * 1e3, 4),
+                event_ms_per_step=round(ev_ms / steps, 4), updates_per_s=ups,
+                step_frac=round(ups * alg_step / 1e9 / HBM_PEAK_GBS, 4),
+                step_frac_is=f"modelled: {alg_step:g} B per update / 8 TB/s",
+                moved_frac=round(ups * moved_step / 1e9 / HBM_PEAK_GBS, 4), moved_bytes_per_update=moved_step,
+                dominant=dict(kernel=kind, avg_launch_ms=round(kms / kcnt, 4), launches_per_step=round(kcnt / psteps, 2),
+                              bytes_per_stream_cell=table[kind], gbs=round(k_gbs, 1), frac=round(k_gbs / HBM_PEAK_GBS, 4)),
+                per_kind_ms={k: round(v[0] / v[1], 4) for k, v in prof.items()},
+                dumps_crossed=int(max(r.current_dumps for r in st)),
+                wall_s=round(time.perf_counter() - t_enter, 1))
+
+
+def extra_configs(wanted, budget_s):
+    sampled = lambda n, scheme: f'\n[sampling]\nseeds = "1 to {n}"\nscheme = "{scheme}"\n'   # noqa: E731
+    plane_toml = ('axis_length = 60.0\nfinal_sim_time = 2000\ncfl = 0.1\nnum_data_dumps = 64\ntotal_mass = 3e16\nhbar_ = 0.01\n'
+                  'ntot = 1e10\nsim_name = "planeWave3d_e10_sym"\nk2_cutoff = 0.95\nalias_threshold = 0.001\ndims = 3\nsize = 256\n'
+                  '[ics]\ntype = "UserSpecified"\npath = "regenerated-at-size-256"\n' + sampled(64, "Wigner"))
+    specs = {
+        "c2_128_1stream": lambda: run_config(
+            "c2_128_1stream", "examples/spherical-tophat.toml, size 128, fp64, mean-field stream only, static box",
+            TOPHAT_TOML.format(name="spherical-tophat", size=128, sampling="", cosmology=""), 128, 1, 0, "f64", False, None,
+            steps=200, warmup=10),
+        "c2_128_64streams": lambda: run_config(
+            "c2_128_64streams", "examples/spherical-tophat.toml, size 128, fp64, 64 Husimi streams, static box",
+            TOPHAT_TOML.format(name="spherical-tophat", size=128, sampling=sampled(64, "Husimi"), cosmology=""), 128, 64, 64, "f64",
+            False, "Husimi", steps=50, warmup=5),
+        "c3_256_64streams": lambda: run_config(
+            "c3_256_64streams", "tomls/planeWave3d_e10_sym.toml, size 256, fp64, 64 Wigner streams in sub-batches of 32, static box",
+            plane_toml, 256, 64, 32, "f64", False, "Wigner", steps=15, warmup=2, psi0=plane_wave_psi(256)),
+        "c5_512_f32_expanding_64streams": lambda: run_config(
+            "c5_512_f32_expanding_64streams",
+            "examples/spherical-tophat-cosmo.toml, size 512, fp32, expanding box, 64 Husimi streams in sub-batches of 32 "
+            "(one GPU's share of 512), host scale-factor loop between msm_step_begin and msm_step_end",
+            TOPHAT_TOML.format(name="spherical-tophat-cosmo", size=512, sampling=sampled(64, "Husimi"), cosmology=TOPHAT_COSMOLOGY),
+            512, 64, 32, "f32", True, "Husimi", steps=10, warmup=2),
+    }
+    out, t0 = {}, time.perf_counter()
+    for name, fn in specs.items():
+        if wanted and name.split("_")[0] not in wanted and name not in wanted:
+            continue
+        if time.perf_counter() - t0 > budget_s:
+            out[name] = dict(skipped=f"the --extra-budget-s of {budget_s:g} s was spent by the configurations before it")
+            continue
+        try:
+            out[name] = fn()
+        except Exception as e:          # a configuration that cannot run must not take the headline line with it
+            out[name] = dict(error=f"{type(e).__name__}: {e}")
+    return out
+
 
 
 def self_launch(args):
@@ -153,6 +344,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="total streams over all GPUs")
     ap.add_argument("--batch", type=int, default=128, help="streams per kernel launch (sub-batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--configs", default="all", help="all | comma list of headline, c2, c3, c5 (extras run with one GPU only)")
+    ap.add_argument("--extra-budget-s", type=float, default=200.0, help="wall-time bound of the extra configurations")
     args = ap.parse_args()
 
     force_dist = os.environ.get("MSM_BENCH_FORCE_DIST") == "1"   # rehearses the RCCL path on one GPU
@@ -165,6 +358,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must equal --gpus")
     N = args.size
     n3 = N ** 3
+    wanted = None if args.configs == "all" else {c.strip() for c in args.configs.split(",") if c.strip()}
 
     store = None
     use_dist = world > 1 or force_dist
@@ -236,7 +430,17 @@ def main():
     aliased = sum(s.aliased for s in st)
 
     if use_dist:
-        elapsed = ev.comm_allreduce([elapsed], msm_amd.Evolver.COMM_MAX)[0]     # the slowest rank's clock
+        # one line per rank on stderr, then the ranks agree on the run's validity: every rank must have taken exactly
+        # the timed steps with no stream aliased, or all of them exit non-zero together
+        print(f"bench.py rank {rank}/{world}: device {local_rank}, {n_local} streams (seeds {seeds[0] if seeds else '-'}.."
+              f"{seeds[-1] if seeds else '-'}), {steps_done} timed steps, {aliased} aliased, {elapsed / max(args.steps, 1) * 1e3:.2f} "
+              f"ms/step here, RCCL from {msm_amd.Evolver.comm_origin()}", file=sys.stderr, flush=True)
+        worst = ev.comm_allreduce([elapsed, -float(steps_done), float(steps_done), float(aliased)], msm_amd.Evolver.COMM_MAX)
+        elapsed = worst[0]                                                      # the slowest rank's clock
+        if -worst[1] != args.steps or worst[2] != args.steps or worst[3] > 0:
+            ev.close()
+            raise SystemExit(f"invalid run (rank {rank}): steps per rank between {int(-worst[1])} and {int(worst[2])} of "
+                             f"{args.steps}, {int(worst[3])} streams aliased on the worst rank")
 
     if rank == 0:
         if steps_done != args.steps or aliased:
@@ -252,10 +456,10 @@ def main():
         # the kernel's own algorithmic bytes: each of its inputs read once, each of its outputs written once
         achieved = moved * cells_per_launch / avg_s / 1e9
         model224 = npass * B_ALG_PASS * cells_per_launch / avg_s / 1e9
-        traffic = measured_traffic(kind, two_pass, cells_per_launch, n3)             # PMC counters, or null
+        traffic, traffic_src = measured_traffic(kind, two_pass, cells_per_launch, n3)   # PMC counters, or null
         b_moved_step = B_MOVED_STEP_TWO_PASS if two_pass else B_MOVED_STEP_GENERIC
         roofline = dict(bound="hbm", kernel=kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         traffic_gbs=round(traffic / avg_s / 1e9, 1) if traffic else None,
                         achievable_peak=HBM_COPY_GBS, achievable_frac=round(achieved / HBM_COPY_GBS, 4),
                         alg_bytes_per_launch=moved * cells_per_launch,
@@ -284,6 +488,9 @@ def main():
                        "density_allreduce": use_dist, "event_ms_per_step": ev_ms / args.steps},
             "roofline": roofline,
         }
+        ev.close()
+        if world == 1 and not use_dist and (wanted is None or wanted - {"headline"}):
+            out["extra_configs"] = extra_configs(None if wanted is None else wanted - {"headline"}, args.extra_budget_s)
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(out), flush=True)

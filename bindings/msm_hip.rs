@@ -66,6 +66,7 @@ extern "C" {
     pub fn msm_synth_allreduce(ctx: *mut MsmCtx, slot: i32) -> i32;
     // several GPUs: RCCL inside the library
     pub fn msm_comm_unique_id(id_out: *mut u8 /* [128] */) -> i32;
+    pub fn msm_comm_origin() -> *const core::ffi::c_char;
     pub fn msm_comm_init(ctx: *mut MsmCtx, id: *const u8, rank: i32, world: i32) -> i32;
     pub fn msm_comm_allreduce_f64(ctx: *mut MsmCtx, values: *mut f64, n: i32, op: i32) -> i32;
     pub fn msm_mean_density_begin(ctx: *mut MsmCtx, total_streams: i64) -> i32;

@@ -207,12 +207,14 @@ int32_t msm_synth_release(msm_ctx* ctx, int32_t slot);
 /* msm_synth_qx for callers that cannot allocate (code under HIP graph capture, tight monitoring loops,
  * harnesses that forbid hipMalloc); it has no counterpart in the reference.  Same value as msm_synth_qx,
  * bit for bit, but nothing is allocated, freed, copied to the host or waited for: the reduction's partial
- * sums live in a fixed 16-KiB workspace inside the library (one copy per GPU, held until the process ends),
+ * sums live in a fixed 16-KiB workspace inside the library (one copy per GPU and precision -- the MSM_F64 and
+ * MSM_F32 engines each hold their own -- kept until the process ends),
  * and {Re Qx, Im Qx} is written to `device_out2`, two doubles the GPU can address (device memory, or pinned
  * host memory from msm_host_alloc), when the context's stream reaches the call (msm_sync to wait).
  * Limit: grids of at most 2^30 cells (1024^3); larger ones are rejected with MSM_ERR_INVALID.
  * The workspace is overwritten completely by every call, so nothing has to be cleared, but it is shared by
- * every context on the same GPU: calls that overlap in time on one GPU (different streams) race. */
+ * every context of the same precision on the same GPU: such calls that overlap in time on one GPU (different
+ * streams) race. */
 int32_t msm_synth_qx_noalloc(msm_ctx* ctx, int32_t slot, double* device_out2);
 
 /* Several GPUs: one process and one context per GPU, the seed streams partitioned by the caller
@@ -235,9 +237,21 @@ int32_t msm_synth_qx_noalloc(msm_ctx* ctx, int32_t slot, double* device_out2);
  *   valid until the next call.
  * msm_synth_allreduce: sums slot `slot` of the in-situ synthesizer (fields and stream count) over the
  *   ranks; collective, a rank that has accumulated nothing contributes zeros.  Afterwards
- *   msm_synth_fetch / msm_synth_qx on any rank return the ensemble's products. */
+ *   msm_synth_fetch / msm_synth_qx on any rank return the ensemble's products.
+ * ORDER RULE.  A context has one communicator and enqueues every collective on one communication stream of
+ * its own, in the order the host issues the calls (the compute stream meets it through events).  RCCL matches
+ * the n-th collective of a communicator on one rank with the n-th on every other rank, so all ranks must issue
+ * the collective calls of their contexts -- msm_comm_init, msm_comm_allreduce_f64, msm_synth_allreduce, and,
+ * once msm_mean_density_begin is on, every msm_step / msm_step_end -- in the same host order and the same
+ * number of times; a rank that issues one more, one fewer, or two in the other order leaves all ranks waiting
+ * in the collective.  msm_mean_density and the other calls are local.
+ * msm_comm_origin: which shared object the RCCL entry points were bound from ("librccl.so.1 (already loaded)",
+ *   a path, ...), or the reason none could be bound; diagnostic text for a launcher's per-rank log.  Binds librccl
+ *   if no earlier call has.
+ */
 #define MSM_COMM_ID_BYTES 128
 int32_t msm_comm_unique_id(void* id_out);
+const char* msm_comm_origin(void);
 int32_t msm_comm_init(msm_ctx* ctx, const void* id, int32_t rank, int32_t world);
 int32_t msm_comm_allreduce_f64(msm_ctx* ctx, double* values, int32_t n, int32_t op);
 int32_t msm_mean_density_begin(msm_ctx* ctx, int64_t total_streams);

@@ -79,6 +79,7 @@ SYMBOLS = {
     "msm_synth_qx_noalloc": (C.c_int32, [_P, C.c_int32, _P]),
     "msm_synth_release": (C.c_int32, [_P, C.c_int32]),
     "msm_comm_unique_id": (C.c_int32, [_P]),
+    "msm_comm_origin": (C.c_char_p, []),
     "msm_comm_init": (C.c_int32, [_P, _P, C.c_int32, C.c_int32]),
     "msm_comm_allreduce_f64": (C.c_int32, [_P, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
     "msm_mean_density_begin": (C.c_int32, [_P, C.c_int64]),
@@ -111,3 +112,20 @@ def load() -> C.CDLL:
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the device sources (msm_amd/csrc/*.hip, *.inc, *.hpp, sorted by name): ties a committed profile
+    summary to the kernels it was taken from.  Empty when the sources are not present beside the library."""
+    import glob
+    import hashlib
+    src = os.path.join(_HERE, "csrc")
+    names = sorted(n for pat in ("*.hip", "*.inc", "*.hpp") for n in glob.glob(os.path.join(src, pat)))
+    if not names:
+        return ""
+    h = hashlib.sha256()
+    for n in names:
+        h.update(os.path.basename(n).encode() + b"\0")
+        with open(n, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()

@@ -263,6 +263,17 @@ int32_t msm_comm_unique_id(void* id_out) {
         return MSM_ERR_INVALID;
     }
 }
+const char* msm_comm_origin(void) {
+    static thread_local std::string text;
+    try {
+        std::string err;
+        const msm::Rccl* r = msm::rccl(err);
+        text = r ? r->origin : err;
+    } catch (...) {
+        return "";
+    }
+    return text.c_str();
+}
 int32_t msm_comm_init(msm_ctx* ctx, const void* id, int32_t rank, int32_t world) {
     MSM_CHECK_CTX(ctx);
     MSM_CALL(ctx, ctx->eng->comm_init(id, rank, world, ctx->err));

@@ -539,7 +539,8 @@ class Engine final : public IEngine {
     const Rccl* rccl_ = nullptr;
     void* comm_ = nullptr;
     int comm_rank_ = 0, comm_world_ = 1;
-    hipStream_t comm_stream_ = nullptr;                 // collectives of the per-step density run beside the next step
+    hipStream_t comm_stream_ = nullptr;                 // every collective runs here (the per-step density beside the next step)
+    hipEvent_t comm_ev_ = nullptr;                      // compute stream -> communication stream
     static constexpr int COMM_SMALL = 64;
     double *comm_small_d_ = nullptr, *comm_small_h_ = nullptr;
     // per-step ensemble density: two sum buffers used alternately, so that the all-reduce of step i overlaps step i + 1
@@ -594,6 +595,7 @@ void Engine::release() {
     if (mean_out_) { (void)hipFree(mean_out_); mean_out_ = nullptr; }
     if (comm_small_d_) { (void)hipFree(comm_small_d_); comm_small_d_ = nullptr; }
     if (comm_small_h_) { (void)hipHostFree(comm_small_h_); comm_small_h_ = nullptr; }
+    if (comm_ev_) { (void)hipEventDestroy(comm_ev_); comm_ev_ = nullptr; }
     if (comm_stream_) { (void)hipStreamDestroy(comm_stream_); comm_stream_ = nullptr; }
     if (copy_stream_) {
         (void)hipStreamSynchronize(copy_stream_);
@@ -1647,10 +1649,24 @@ int Engine::comm_init(const void* id, int rank, int world, std::string& err) {
     const int rc = rccl_->comm_init_rank(&comm_, world, cid, rank);   // meets the other ranks
     if (rc != 0) { comm_ = nullptr; return nccl_fail(rc, "ncclCommInitRank", err); }
     comm_rank_ = rank; comm_world_ = world;
-    HIP_TRY(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&comm_small_d_, sizeof(double) * COMM_SMALL));
-    HIP_TRY(hipHostMalloc((void**)&comm_small_h_, sizeof(double) * COMM_SMALL));
-    return MSM_OK;
+    // all or nothing: a failure below leaves the context without a communicator, so that a second call is a clean
+    // retry instead of "called twice" on half-built resources
+    const int rs = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&comm_ev_, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void**)&comm_small_d_, sizeof(double) * COMM_SMALL));
+        HIP_TRY(hipHostMalloc((void**)&comm_small_h_, sizeof(double) * COMM_SMALL));
+        return MSM_OK;
+    }();
+    if (rs != MSM_OK) {
+        (void)rccl_->comm_destroy(comm_);
+        comm_ = nullptr;
+        if (comm_small_d_) { (void)hipFree(comm_small_d_); comm_small_d_ = nullptr; }
+        if (comm_small_h_) { (void)hipHostFree(comm_small_h_); comm_small_h_ = nullptr; }
+        if (comm_ev_) { (void)hipEventDestroy(comm_ev_); comm_ev_ = nullptr; }
+        if (comm_stream_) { (void)hipStreamDestroy(comm_stream_); comm_stream_ = nullptr; }
+    }
+    return rs;
 }
 
 int Engine::mean_density_begin(long long total_streams, std::string& err) {
@@ -1659,12 +1675,13 @@ int Engine::mean_density_begin(long long total_streams, std::string& err) {
     if (total_streams < 1) { err = "total_streams must be >= 1"; return MSM_ERR_INVALID; }
     mean_total_ = total_streams;
     if (mean_on_) return MSM_OK;
+    // resources that a failed earlier call has already created are kept and reused, never allocated twice
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc((void**)&mean_buf_[i], sizeof(double) * n3_));
-        HIP_TRY(hipEventCreateWithFlags(&dens_ready_[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&comm_done_[i], hipEventDisableTiming));
+        if (!mean_buf_[i]) HIP_TRY(hipMalloc((void**)&mean_buf_[i], sizeof(double) * n3_));
+        if (!dens_ready_[i]) HIP_TRY(hipEventCreateWithFlags(&dens_ready_[i], hipEventDisableTiming));
+        if (!comm_done_[i]) HIP_TRY(hipEventCreateWithFlags(&comm_done_[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipMalloc((void**)&mean_out_, sizeof(double) * n3_));
+    if (!mean_out_) HIP_TRY(hipMalloc((void**)&mean_out_, sizeof(double) * n3_));
     mean_on_ = true;
     mean_next_ = 0; mean_last_ = -1;
     step_dens_ = nullptr;
@@ -1703,16 +1720,18 @@ int Engine::mean_density(double* host, void** dev, std::string& err) {
     return MSM_OK;
 }
 
+// Every collective of a context is enqueued on its communication stream, in the order the host issues them: one
+// communicator, one stream.  The compute stream meets it through events only.
 int Engine::comm_allreduce_f64(double* vals, int n, int op, std::string& err) {
     if (!comm_) { err = "msm_comm_init first"; return MSM_ERR_STATE; }
     if (!vals || n < 1 || n > COMM_SMALL) { err = "1 to 64 values"; return MSM_ERR_INVALID; }
     if (op != COMM_SUM && op != COMM_MAX && op != COMM_MIN) { err = "op must be sum (0), max (2) or min (3)"; return MSM_ERR_INVALID; }
     std::memcpy(comm_small_h_, vals, sizeof(double) * n);
-    HIP_TRY(hipMemcpyAsync(comm_small_d_, comm_small_h_, sizeof(double) * n, hipMemcpyHostToDevice, stream_));
-    const int rc = rccl_->all_reduce(comm_small_d_, comm_small_d_, (size_t)n, COMM_F64, op, comm_, stream_);
+    HIP_TRY(hipMemcpyAsync(comm_small_d_, comm_small_h_, sizeof(double) * n, hipMemcpyHostToDevice, comm_stream_));
+    const int rc = rccl_->all_reduce(comm_small_d_, comm_small_d_, (size_t)n, COMM_F64, op, comm_, comm_stream_);
     if (rc != 0) return nccl_fail(rc, "ncclAllReduce", err);
-    HIP_TRY(hipMemcpyAsync(comm_small_h_, comm_small_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemcpyAsync(comm_small_h_, comm_small_d_, sizeof(double) * n, hipMemcpyDeviceToHost, comm_stream_));
+    HIP_TRY(hipStreamSynchronize(comm_stream_));
     std::memcpy(vals, comm_small_h_, sizeof(double) * n);
     return MSM_OK;
 }
@@ -1729,10 +1748,13 @@ int Engine::synth_allreduce(int slot, std::string& err) {
         HIP_TRY(hipMemsetAsync(sl.sums, 0, sizeof(double2) * 4 * n3_, stream_));
         sl.count = 0;
     }
-    int rc = rccl_->all_reduce(sl.sums, sl.sums, 8 * n3_, COMM_F64, COMM_SUM, comm_, stream_);
+    // the accumulations were enqueued on the compute stream: the collective starts behind them
+    HIP_TRY(hipEventRecord(comm_ev_, stream_));
+    HIP_TRY(hipStreamWaitEvent(comm_stream_, comm_ev_, 0));
+    int rc = rccl_->all_reduce(sl.sums, sl.sums, 8 * n3_, COMM_F64, COMM_SUM, comm_, comm_stream_);
     if (rc != 0) return nccl_fail(rc, "ncclAllReduce", err);
     double c = (double)sl.count;
-    if (int r2 = comm_allreduce_f64(&c, 1, COMM_SUM, err)) return r2;   // synchronises the stream
+    if (int r2 = comm_allreduce_f64(&c, 1, COMM_SUM, err)) return r2;   // waits for the communication stream: the sums are final
     sl.count = (long long)(c + 0.5);
     return MSM_OK;
 }

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "cosmo.hpp"
+#include "expanding_loop.hpp"
 #include "ics.hpp"
 #include "npy_io.hpp"
 #include "params.hpp"
@@ -145,6 +146,61 @@ double msmh_dt_from_dtau(const double cosmo[5], int has_max_dloga, double t_elap
     ScaleFactorSolver s(c);
     s.step(t_elapsed);
     return calculate_dt_from_dtau(s, c, tau, t_elapsed, dtau);
+}
+
+// ---- the expanding-box host loop of host/expanding_loop.hpp for callers outside the CLI (benchmarks, tests) ----
+// precision 0: time and tau kept in double, 1: in float (the type the reference would be compiled with)
+struct msmh_expanding {
+    int precision;
+    ExpandingHost<double>* d;
+    ExpandingHost<float>* f;
+};
+
+void* msmh_expanding_new(const double cosmo[5], int has_max_dloga, int precision, int n_streams, double time0,
+                         double final_sim_time, unsigned num_data_dumps) {
+    try {
+        if (n_streams < 1 || num_data_dumps < 1) { g_err = "n_streams and num_data_dumps must be >= 1"; return nullptr; }
+        const CosmologyParameters c = cosmo_from(cosmo, has_max_dloga);
+        auto* h = new msmh_expanding{precision, nullptr, nullptr};
+        if (precision == 0) h->d = new ExpandingHost<double>(c, n_streams, time0, final_sim_time, num_data_dumps);
+        else h->f = new ExpandingHost<float>(c, n_streams, time0, final_sim_time, num_data_dumps);
+        return h;
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void msmh_expanding_free(void* p) {
+    auto* h = (msmh_expanding*)p;
+    if (!h) return;
+    delete h->d;
+    delete h->f;
+    delete h;
+}
+// inputs of msm_step_begin and the snapped tau of msm_step_end, from every stream's count of dumps written
+int msmh_expanding_begin(void* p, const int* current_dumps, double* a_now, double* tau_to_next_dump, double* snapped_tau) {
+    try {
+        auto* h = (msmh_expanding*)p;
+        if (h->d) h->d->begin(current_dumps, a_now, tau_to_next_dump, snapped_tau);
+        else h->f->begin(current_dumps, a_now, tau_to_next_dump, snapped_tau);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// the two half-kicks: advances the solvers of active streams by the device's d tau, fills msm_step_end's inputs
+int msmh_expanding_advance(void* p, const double* dtau, const int* active, double* kick_a, double* new_time, double* new_tau) {
+    try {
+        auto* h = (msmh_expanding*)p;
+        if (h->d) h->d->advance(dtau, active, kick_a, new_time, new_tau);
+        else h->f->advance(dtau, active, kick_a, new_time, new_tau);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// the clocks the device reports after msm_step_end (snapped at dumps), for all streams
+int msmh_expanding_commit(void* p, const double* time, const double* tau) {
+    auto* h = (msmh_expanding*)p;
+    const int n = h->d ? h->d->streams() : h->f->streams();
+    for (int s = 0; s < n; ++s) {
+        if (h->d) h->d->commit(s, time[s], tau[s]);
+        else h->f->commit(s, time[s], tau[s]);
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -32,12 +32,14 @@
 #include <mutex>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../../include/msm.h"
 #include "cosmo.hpp"
+#include "expanding_loop.hpp"
 #include "ics.hpp"
 #include "npy_io.hpp"
 #include "params.hpp"
@@ -370,31 +372,19 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
     for (int s = 0; s < ns; ++s) if (resumed[s] < 0) { dump(s, 0); synthesize(s, 0); }   // main.rs:61
     flush_synth();
 
-    // ---- expanding-box host state (simulation_object.rs:726-760, :939-990)
-    std::vector<ScaleFactorSolver> solvers;
-    std::map<double, double> tau_cache;
-    auto tau_of = [&](double t) {
-        auto it = tau_cache.find(t);
-        if (it == tau_cache.end()) it = tau_cache.emplace(t, get_tau(t, *toml.cosmology)).first;
-        return it->second;
-    };
-    std::vector<T> time(ns, (T)cfg.time), tau(ns, (T)0);
-    for (int s = 0; s < ns; ++s)
-        if (resumed[s] >= 0) time[s] = (T)resumed[s] * (T)toml.final_sim_time / (T)toml.num_data_dumps;   // the snapped dump time (:628-630)
-    if (args.expanding) {
-        solvers.assign(ns, ScaleFactorSolver(*toml.cosmology));
-        for (int s = 0; s < ns; ++s) {
-            if (resumed[s] > 0) solvers[s].step((double)time[s] - cfg.time);   // a(t) re-integrated from the start
-            tau[s] = (T)tau_of((double)time[s]);
-        }
+    // ---- expanding-box host state (simulation_object.rs:726-760, :939-990): host/expanding_loop.hpp
+    std::unique_ptr<ExpandingHost<T>> xhost;
+    if (args.expanding) xhost = std::make_unique<ExpandingHost<T>>(*toml.cosmology, ns, cfg.time, toml.final_sim_time, toml.num_data_dumps);
+    for (int s = 0; s < ns; ++s) {
+        if (resumed[s] < 0) continue;
+        const T t_dump = (T)resumed[s] * (T)toml.final_sim_time / (T)toml.num_data_dumps;   // the snapped dump time (:628-630)
+        if (xhost) xhost->place_at_dump(s, resumed[s]);
+        check(ctx, msm_set_clock(ctx, s, (double)t_dump, xhost ? (double)xhost->tau(s) : 0.0, resumed[s]), "msm_set_clock");
     }
-    for (int s = 0; s < ns; ++s)
-        if (resumed[s] >= 0) check(ctx, msm_set_clock(ctx, s, (double)time[s], (double)tau[s], resumed[s]), "msm_set_clock");
 
     std::vector<msm_stream_status> st(ns), prev(ns);
     check(ctx, msm_get_status(ctx, prev.data(), ns), "msm_get_status");
     const auto t_loop = std::chrono::steady_clock::now();
-    const T tf = (T)toml.final_sim_time, nd = (T)toml.num_data_dumps;
     bool aliased_here = false;
     for (;;) {
         bool any_active = false;
@@ -418,30 +408,14 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
         if (!args.expanding) {
             check(ctx, msm_step(ctx), "msm_step");
         } else {
-            std::vector<double> a_now(ns), tau_next(ns), kick_a(ns), new_time(ns), new_tau(ns), snapped(ns);
-            for (int s = 0; s < ns; ++s) {
-                a_now[s] = solvers[s].get_a();
-                const T ttnd = (T)(prev[s].current_dumps + 1) * tf / nd - time[s];
-                tau_next[s] = (double)((T)tau_of((double)(time[s] + ttnd)) - tau[s]);
-                snapped[s] = (double)(T)tau_of((double)((T)(prev[s].current_dumps + 1) * tf / nd));
-            }
+            std::vector<double> a_now(ns), tau_next(ns), kick_a(ns), new_time(ns), new_tau(ns), snapped(ns), dtau(ns);
+            std::vector<int> dumps(ns), live(ns);
+            for (int s = 0; s < ns; ++s) { dumps[s] = prev[s].current_dumps; live[s] = prev[s].active; }
+            xhost->begin(dumps.data(), a_now.data(), tau_next.data(), snapped.data());
             check(ctx, msm_step_begin(ctx, a_now.data(), tau_next.data()), "msm_step_begin");
             check(ctx, msm_get_status(ctx, st.data(), ns), "msm_get_status");
-            for (int s = 0; s < ns; ++s) {
-                if (!prev[s].active) { kick_a[s] = 0; new_time[s] = (double)time[s]; new_tau[s] = (double)tau[s]; continue; }
-                const T dtau = (T)st[s].dt;
-                T a_sum = 0, t_new = time[s], tau_new = tau[s];
-                for (int half = 0; half < 2; ++half) {
-                    a_sum += (T)solvers[s].get_a();
-                    const T dt_myr = (T)calculate_dt_from_dtau(solvers[s], *toml.cosmology, (double)tau_new, (double)t_new, (double)(dtau / (T)2.0));
-                    solvers[s].step((double)dt_myr);
-                    t_new = t_new + dt_myr;
-                    tau_new = tau_new + dtau / (T)2.0;
-                }
-                kick_a[s] = (double)a_sum;
-                new_time[s] = (double)t_new;
-                new_tau[s] = (double)tau_new;
-            }
+            for (int s = 0; s < ns; ++s) dtau[s] = st[s].dt;
+            xhost->advance(dtau.data(), live.data(), kick_a.data(), new_time.data(), new_tau.data());
             check(ctx, msm_step_end(ctx, kick_a.data(), new_time.data(), new_tau.data(), snapped.data()), "msm_step_end");
         }
         check(ctx, msm_get_status(ctx, st.data(), ns), "msm_get_status");
@@ -458,12 +432,11 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
                 msm_destroy(ctx);
                 return 101;
             }
-            time[s] = (T)st[s].time;
-            tau[s] = (T)st[s].tau;
+            if (xhost) xhost->commit(s, st[s].time, st[s].tau);
             if (st[s].dump) {
                 dump(s, st[s].current_dumps);
                 synthesize(s, st[s].current_dumps);
-                if (args.expanding) std::printf("(%s) z = %g  [%d/%u]\n", streams[s].sim_name.c_str(), 1.0 / solvers[s].get_a() - 1.0, st[s].current_dumps, toml.num_data_dumps);
+                if (args.expanding) std::printf("(%s) z = %g  [%d/%u]\n", streams[s].sim_name.c_str(), 1.0 / xhost->a(s) - 1.0, st[s].current_dumps, toml.num_data_dumps);
                 else std::printf("(%s) t = %g  [%d/%u]\n", streams[s].sim_name.c_str(), st[s].time, st[s].current_dumps, toml.num_data_dumps);
             }
             if (!st[s].active && args.verbose)

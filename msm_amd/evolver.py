@@ -254,6 +254,11 @@ class Evolver:
             raise MsmError(f"msm_comm_unique_id failed ({rc}): {lib.msm_last_error(None).decode()}")
         return buf.raw
 
+    @staticmethod
+    def comm_origin() -> str:
+        """Which shared object RCCL was bound from (or why none could be)."""
+        return L.load().msm_comm_origin().decode()
+
     def comm_init(self, comm_id: bytes, rank: int, world: int):
         if len(comm_id) != 128:
             raise ValueError("the communicator id is 128 bytes")

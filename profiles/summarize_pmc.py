@@ -5,11 +5,19 @@ usage: python profiles/summarize_pmc.py <fetch counter_collection.csv> <write co
 Corrections for gfx950 (MI355X): both counters are in KiB; FETCH_SIZE reports one half of
 the bytes of wide coalesced streaming reads (8-16 B per lane), so it is doubled; WRITE_SIZE
 is exact for such stores.  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch.
+
+The summary carries `_meta`: the hash of the device sources the profiled library was built from
+(msm_amd._lib.kernel_source_hash) and, where git is at hand, the commit.  bench.py reports these bytes as
+`roofline.traffic` only while that hash equals the one of the tree it runs from.
 """
 import collections
 import csv
 import json
+import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_kernel(path):
@@ -30,7 +38,15 @@ def main():
         f, w = fetch[k], write.get(k, 0.0)
         out[short] = dict(launches=nf[k], fetch_size_kib=round(f, 1), write_size_kib=round(w, 1),
                           hbm_bytes_per_launch=int((2 * f + w) * 1024))
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    sys.path.insert(0, ROOT)
+    from msm_amd._lib import kernel_source_hash
+    meta = dict(kernel_source_hash=kernel_source_hash())
+    try:
+        meta["git_sha"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True,
+                                         timeout=10).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        meta["git_sha"] = None          # the GPU box holds a snapshot without .git
+    json.dump(dict(out, _meta=meta), open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:8.3f} GB/launch")
 

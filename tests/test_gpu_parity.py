@@ -159,6 +159,18 @@ def test_static_steps_tophat_f64(N):
         assert abs(ev.status()[0].alias_mass - float(sim.check_alias()[0])) < 1e-20
 
 
+def test_static_steps_plain_launches(monkeypatch):
+    """Small grids replay their step from a captured HIP graph; MSM_GRAPH=0 takes the plain launch path with the same
+    kernels.  Both must follow the oracle, so that a change to the capture cannot hide a launch-path bug."""
+    monkeypatch.setenv("MSM_GRAPH", "0")
+    N = 16
+    sim = oracle_sim(TOPHAT, N)
+    with Evolver(size=N, n_streams=1, **TOPHAT) as ev:
+        ev.set_psi(0, sim.psi)
+        check_steps(ev, 0, sim, 10, 1e-11)
+        assert abs(ev.status()[0].alias_mass - float(sim.check_alias()[0])) < 1e-20
+
+
 def test_static_steps_128_f64():
     N = 128
     sim = oracle_sim(dict(TOPHAT, cfl=0.05), N)   # small cfl: dt limited by the kinetic bound, not the dump

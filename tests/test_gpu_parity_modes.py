@@ -137,6 +137,49 @@ def test_two_pass_256_static_vs_numpy_oracle(oracle_256_static, precision, tol, 
             assert rel_err(ev.get_potential(s), phi[s]) < (1e-11 if precision == "f64" else 2e-3), s
 
 
+def test_benchmark_workload_256_vs_numpy_oracle():
+    """The headline benchmark's own inputs at its own size (bench.py: plane-wave ICs of sim.py regenerated at N = 256,
+    tomls/planeWave3d_e10_sym.toml parameters, Wigner noise per stream seed): the sampled psi_0 of two seeds against the
+    oracle's sampler (ics.rs:560-602), then two steps of both streams against the numpy oracle."""
+    from msm_amd.ics import plane_wave_psi
+    PLANE = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=64, total_mass=3e16,
+                 hbar_=0.01, ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)      # = bench.py PLANE
+    N, seeds = 256, (1, 2)
+    psi0 = plane_wave_psi(N)
+    assert np.array_equal(psi0, o.plane_wave_ics(N))
+    o.FFT_WORKERS = 8
+    try:
+        toml = dict(PLANE, sim_name="t", dims=3, size=N, ics=TOPHAT_ICS)       # ics unused: psi is handed over below
+        params = [list(o.simulation_iter(toml))[-1] for _ in seeds]
+        want0 = [o.sample_quantum_perturbation(psi0, 60.0 / N, 3, PLANE["total_mass"], PLANE["total_mass"] / PLANE["ntot"],
+                                               "Wigner", seed) for seed in seeds]
+        sims = [o.SimulationObject(p, psi=w) for p, w in zip(params, want0)]
+        with Evolver(size=N, n_streams=2, **PLANE) as ev:
+            assert ev.derived()["transform_passes_mode"] == 2.0
+            ev.set_psi(0, psi0)
+            ev.copy_psi(1, 0)
+            for s, seed in enumerate(seeds):
+                ev.sample(s, "Wigner", seed)
+            for s in range(2):
+                noise = np.max(np.abs(want0[s] - psi0))
+                assert noise > 0 and np.max(np.abs(ev.get_psi(s) - want0[s])) < 1e-12 * noise + 1e-15 * np.max(np.abs(psi0)), s
+            for i in range(2):
+                ev.update()
+                st = ev.status()
+                for s, sim in enumerate(sims):
+                    info = sim.update()
+                    assert abs(st[s].dt / float(info["dt"]) - 1) <= 1e-12, (i, s, st[s].dt, info["dt"])
+                    assert bool(st[s].dump) == info["dump"] and abs(st[s].time / float(info["time"]) - 1) <= 1e-12
+                    assert abs(st[s].max_phi / float(info["max_phi"]) - 1) <= 1e-11 and st[s].aliased == 0
+                    assert abs(st[s].alias_mass - float(info["alias_mass"])) <= max(1e-4 * float(info["alias_mass"]), 1e-20)
+            assert st[0].dt != st[1].dt                   # two seeds, two trajectories
+            for s, sim in enumerate(sims):
+                assert rel_err(ev.get_psi(s), sim.psi) < 1e-11, s
+                assert rel_err(ev.get_psik(s), sim.psik) < 1e-11, s
+    finally:
+        o.FFT_WORKERS = 0
+
+
 @pytest.fixture(scope="module")
 def oracle_256_expanding():
     o.FFT_WORKERS = 8

@@ -260,3 +260,47 @@ def test_dt_from_dtau(host):
     want = sim._calculate_dt_from_dtau(3e-4)
     got = host.msmh_dt_from_dtau(cosmo, 1, 12.5, float(sim.parameters.tau), 3e-4)
     assert abs(got / want - 1) < 1e-12
+
+
+@pytest.mark.parametrize("precision,dtype,rtol", [("f64", np.float64, 1e-12), ("f32", np.float32, 1e-6)])
+def test_expanding_host_loop_matches_oracle_bookkeeping(precision, dtype, rtol):
+    """host/expanding_loop.hpp (what msm-simulator and the benchmark put between msm_step_begin and msm_step_end) against
+    the same scalars taken from an oracle object (simulation_object.rs:726-760, :939-990) over six steps, two streams;
+    d tau comes from the oracle's own step, the streams cross dump times on the way."""
+    import copy
+
+    import expanding_host as xh
+    from msm_amd.expanding import ExpandingHost
+
+    cosmo = dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01)
+    toml = dict(axis_length=30.0, final_sim_time=0.6, cfl=0.05, num_data_dumps=3, total_mass=1e11, hbar_=0.05, ntot=1e6,
+                sim_name="t", k2_cutoff=0.95, alias_threshold=0.02, dims=3, size=8,
+                ics=dict(type="SphericalTophat", radius=5.0, slope=50.0, delta=100.0), cosmology=cosmo,
+                sampling=dict(seeds="1", scheme="Husimi"))
+    sims = [o.SimulationObject(p) for p in o.simulation_iter(toml, expanding=True, dtype=dtype)]
+    host = ExpandingHost(cosmo, 2, precision, 0.6, 3)
+    dumps_seen = 0
+    for step in range(6):
+        live = [1 if sim.not_finished() else 0 for sim in sims]
+        if not any(live):
+            break
+        pre = [xh.step_inputs(sim) for sim in sims]
+        a_now, tau_next, snapped = host.begin([sim.parameters.current_dumps for sim in sims])
+        for s in range(2):
+            if live[s]:
+                assert np.allclose([a_now[s], tau_next[s], snapped[s]], pre[s], rtol=rtol, atol=0), (step, s)
+        dtau = []
+        for s, sim in enumerate(sims):
+            shadow = copy.deepcopy(sim)
+            dtau.append(float(shadow.update()["dt"]) if live[s] else 0.0)
+        post = [xh.half_kicks(sim, dtau[s]) for s, sim in enumerate(sims)]
+        kick_a, new_time, new_tau = host.advance(dtau, live)
+        for s in range(2):
+            if live[s]:
+                assert np.allclose([kick_a[s], new_time[s], new_tau[s]], post[s], rtol=rtol, atol=0), (step, s)
+        for s, sim in enumerate(sims):
+            if live[s]:
+                dumps_seen += int(sim.update()["dump"])
+        host.commit([float(sim.parameters.time) for sim in sims], [float(sim.parameters.tau) for sim in sims])
+    assert dumps_seen >= 2
+    host.close()

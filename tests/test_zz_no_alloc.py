@@ -32,8 +32,13 @@ def _qx_both_ways(ev, n_streams, N, dims, seed0, out_ptr, out):
     return want, complex(out[0], out[1])
 
 
-def test_qx_noalloc_matches_qx_two_calls_second_smaller():
-    with Evolver(size=64, n_streams=3, **TOPHAT) as big, Evolver(size=12, n_streams=2, dims=2, precision="f32", **TOPHAT) as small:
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_qx_noalloc_matches_qx_two_calls_second_smaller(precision):
+    # The library holds one workspace per GPU and precision (the double- and single-precision engines are separate
+    # translation units), so both contexts of a pair have the same precision: the second call really finds the first
+    # call's partial sums in the array it is about to use.
+    with Evolver(size=64, n_streams=3, precision=precision, **TOPHAT) as big, \
+            Evolver(size=12, n_streams=2, dims=2, precision=precision, **TOPHAT) as small:
         p = C.c_void_p()
         big._check(big._lib.msm_host_alloc(16, C.byref(p)), "msm_host_alloc")
         out = np.frombuffer((C.c_char * 16).from_address(p.value), dtype=np.float64)
