@@ -282,7 +282,7 @@ def extra_configs(wanted, budget_s):
         "c2_128_1stream": lambda: run_config(
             "c2_128_1stream", "examples/spherical-tophat.toml, size 128, fp64, mean-field stream only, static box",
             TOPHAT_TOML.format(name="spherical-tophat", size=128, sampling="", cosmology=""), 128, 1, 0, "f64", False, None,
-            steps=200, warmup=10),
+            steps=150, warmup=10),          # (every step of this TOML lands on one of its 200 dumps: the run ends after 200)
         "c2_128_64streams": lambda: run_config(
             "c2_128_64streams", "examples/spherical-tophat.toml, size 128, fp64, 64 Husimi streams, static box",
             TOPHAT_TOML.format(name="spherical-tophat", size=128, sampling=sampled(64, "Husimi"), cosmology=""), 128, 64, 64, "f64",

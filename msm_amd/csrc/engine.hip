@@ -956,13 +956,20 @@ PoisArgs Engine::pois_args(int s0, int nb, const int* act) const {
 }
 
 #ifdef MSM_TQ
-// 512^3 tiling: pass A^-1 of the batch's states -> |psi|^2 of every stream as a real grid (in the potential array) ->
-// pass A of rho_a + i rho_b into W; optionally the ensemble density of the streams in p.active.
+// 512^3 tiling: the batch's states -> pass A^-1 -> |psi|^2 -> pass A of rho_a + i rho_b into W.  The first stream of
+// every pair leaves |psi_a|^2 as a real grid (in the potential array), the second stream's workgroups read it and pack
+// the pair in registers; an unpaired last stream goes through k5_rho_fwd.  With `dens` every stream's |psi|^2 is kept
+// as a grid and summed into the ensemble density of the streams in p.active.
 void Engine::tq_rho_from_state(const PoisArgs& p, int nb, bool dens) {
     const dim3 block(tq::THREADS);
-    k5_inv_rho<<<dim3(tq::A_TILES, (unsigned)nb), block, 0, stream_>>>(p);
+    k5_inv_rho<2><<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), block, 0, stream_>>>(p);
+    if (nb >= 2) {
+        const dim3 grid(tq::A_TILES, (unsigned)(nb / 2));
+        if (dens) k5_inv_rho_pack<1><<<grid, block, 0, stream_>>>(p);
+        else k5_inv_rho_pack<0><<<grid, block, 0, stream_>>>(p);
+    }
     if (dens) k5_dens_from_rho<<<2048, 256, 0, stream_>>>(PHI_, n3_, nb, p.active, p.s0, p.dens);
-    k5_rho_fwd<<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), block, 0, stream_>>>(p);
+    if (nb & 1) k5_rho_fwd<1><<<dim3(tq::A_TILES, 1), block, 0, stream_>>>(p);
 }
 #endif
 

@@ -146,7 +146,7 @@ def test_benchmark_workload_256_vs_numpy_oracle():
                  hbar_=0.01, ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)      # = bench.py PLANE
     N, seeds = 256, (1, 2)
     psi0 = plane_wave_psi(N)
-    assert np.array_equal(psi0, o.plane_wave_ics(N))
+    assert rel_err(psi0, o.plane_wave_ics(N)) < 1e-13     # two restatements of sim.py:124-183, equal to rounding
     o.FFT_WORKERS = 8
     try:
         toml = dict(PLANE, sim_name="t", dims=3, size=N, ics=TOPHAT_ICS)       # ics unused: psi is handed over below
