@@ -368,6 +368,8 @@ def main():
         # timed region, the maximum over the ranks' clocks -- goes through the library's own RCCL communicator.
         import torch            # before the first Evolver: libmsm_hip.so then binds to the HIP runtime torch loaded
         from torch.distributed import TCPStore
+        if os.environ.get("MSM_BENCH_SHARE_GPU") == "1":     # rehearsal on a one-GPU box (with a stand-in for RCCL,
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)   # which refuses two ranks on one device)
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: this node shows {torch.cuda.device_count()} GPU(s), --gpus {args.gpus} needs "
                              f"one per rank")

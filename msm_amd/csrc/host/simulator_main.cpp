@@ -5,7 +5,7 @@
 //
 //   msm-simulator --toml <path> [-v|--verbose] [--test]
 //                 [--expanding] [--precision f64|f32] [--device N] [--batch B] [--synthesize] [--resume]
-//                 [--rank R --world W [--comm-file PATH]] [--wave STREAMS]
+//                 [--rank R --world W [--comm-file PATH]] [--mean-density] [--wave STREAMS]
 //
 // --expanding stands for the reference's cargo feature of the same name (compile-time there).
 // --synthesize also writes the msm-synthesizer's products (synthesizer/src/main.rs:63-187) for the seed
@@ -21,7 +21,15 @@
 //   128-byte id in PATH (a name unique to this launch, on a file system all ranks see), the others wait for it.
 //   They then stop together when a stream aliases anywhere, and --synthesize works across the ranks: the
 //   synthesizer's sums are all-reduced per dump index and rank 0 writes the -combined/ products.
+// --mean-density (with --comm-file): the ensemble density <|psi|^2> over all ranks' seed streams is formed inside every
+//   step and all-reduced beside the next one (msm_mean_density_begin: the synthesizer's psi2, synthesizer/src/lib.rs:217-229,
+//   in situ and per step).  Whenever a step lands every seed stream of every rank on the same dump k, rank 0 writes it
+//   as sim-data/{sim_name}-combined/mean_density_{k:05} (one real NPY array).  The mean-field run is evolved after
+//   the seed streams, in a context of its own (the synthesizer leaves it out, lib.rs:190-193).
+// A rank that fails leaves a note in PATH.abort; a watchdog thread in every other rank sees it and ends that rank with a
+//   non-zero status, also when it is blocked inside a collective.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +61,7 @@ const char* SIM_DATA_FOLDER = "sim-data";           // simulation_object.rs:1116
 
 struct Args {
     std::string toml;
-    bool verbose = false, test = false, expanding = false, synthesize = false, resume = false;
+    bool verbose = false, test = false, expanding = false, synthesize = false, resume = false, mean_density = false;
     int precision = MSM_F64, device = 0, batch = 0, rank = 0, world = 1, wave = 0;
     std::string comm_file;
 };
@@ -80,6 +88,7 @@ Args parse_args(int argc, char** argv) {
         else if (s == "--expanding") a.expanding = true;
         else if (s == "--synthesize") a.synthesize = true;
         else if (s == "--resume") a.resume = true;
+        else if (s == "--mean-density") a.mean_density = true;
         else if (s == "--rank") a.rank = std::atoi(val().c_str());
         else if (s == "--world") a.world = std::atoi(val().c_str());
         else if (s == "--comm-file") a.comm_file = val();
@@ -94,12 +103,69 @@ Args parse_args(int argc, char** argv) {
     if (a.world > 1 && a.synthesize && a.comm_file.empty()) usage("--synthesize over several processes needs --comm-file (the ranks' sums are all-reduced)");
     // a resumed stream has passed dumps whose ensemble sums were never formed in this process
     if (a.resume && a.synthesize) usage("--resume cannot be combined with --synthesize");
+    if (a.mean_density && a.comm_file.empty()) usage("--mean-density needs --comm-file (the density is all-reduced over the communicator; --world 1 is allowed)");
+    if (a.mean_density && a.resume) usage("--resume cannot be combined with --mean-density");
     return a;
 }
 
 void check(msm_ctx* ctx, int rc, const char* what) {
     if (rc != MSM_OK) throw std::runtime_error(std::string(what) + " failed: " + msm_last_error(ctx));
 }
+
+// ---- several ranks: a failing rank must not leave the others waiting in a collective for ever
+std::string abort_marker(const std::string& comm_file) { return comm_file + ".abort"; }
+void leave_abort_note(const Args& a, const std::string& why) {
+    if (a.comm_file.empty()) return;
+    const std::string tmp = abort_marker(a.comm_file) + ".tmp" + std::to_string(a.rank);
+    if (FILE* f = std::fopen(tmp.c_str(), "w")) {
+        std::fprintf(f, "rank %d: %s\n", a.rank, why.c_str());
+        std::fclose(f);
+        std::error_code ec;
+        std::filesystem::rename(tmp, abort_marker(a.comm_file), ec);
+    }
+}
+bool read_abort_note(const std::string& comm_file, std::string& note) {
+    std::error_code ec;
+    if (!std::filesystem::exists(abort_marker(comm_file), ec)) return false;
+    note.clear();
+    if (FILE* f = std::fopen(abort_marker(comm_file).c_str(), "r")) {
+        char buf[512];
+        if (std::fgets(buf, sizeof buf, f)) note = buf;
+        std::fclose(f);
+    }
+    while (!note.empty() && (note.back() == '\n' || note.back() == '\r')) note.pop_back();
+    return true;
+}
+// Polls for another rank's note while this rank works (or waits inside RCCL) and ends the process when one appears.
+class AbortWatch {
+  public:
+    AbortWatch(const Args& a) : on_(!a.comm_file.empty()) {
+        if (!on_) return;
+        th_ = std::thread([this, file = a.comm_file, rank = a.rank] {
+            while (!stop_.load()) {
+                std::string note;
+                if (read_abort_note(file, note)) {
+                    std::fprintf(stderr, "rank %d: stopping, another rank failed (%s)\n", rank, note.c_str());
+                    std::fflush(nullptr);
+                    std::_Exit(1);   // the main thread may be blocked in a collective that will never complete
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+        });
+    }
+    ~AbortWatch() { stop(); }
+    void stop() {
+        if (!on_) return;
+        stop_.store(true);
+        if (th_.joinable()) th_.join();
+        on_ = false;
+    }
+
+  private:
+    bool on_;
+    std::atomic<bool> stop_{false};
+    std::thread th_;
+};
 
 // dump writers: two NPY files per array, written on worker threads, at most 32 in flight
 // (utils/io.rs:34-88, simulation_object.rs:1123-1136)
@@ -198,6 +264,8 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
                     if (f) std::fclose(f);
                     if (ok) break;
                 }
+                std::string note;
+                if (read_abort_note(args.comm_file, note)) throw std::runtime_error("another rank failed before the communicator was formed (" + note + ")");
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) throw std::runtime_error("no communicator id appeared in " + args.comm_file);
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
             }
@@ -210,6 +278,13 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
         if (comm) check(ctx, msm_comm_allreduce_f64(ctx, &v, 1, op), "msm_comm_allreduce_f64");
         return v;
     };
+
+    // per-step ensemble density over every rank's seed streams (this context holds seed streams only then: run())
+    const bool mean_on = comm && args.mean_density;
+    if (mean_on) {
+        const double total = agree((double)ns, 0);
+        check(ctx, msm_mean_density_begin(ctx, (int64_t)(total + 0.5)), "msm_mean_density_begin");
+    }
 
     double derived[8];
     check(ctx, msm_get_derived(ctx, derived), "msm_get_derived");
@@ -385,7 +460,7 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
     std::vector<msm_stream_status> st(ns), prev(ns);
     check(ctx, msm_get_status(ctx, prev.data(), ns), "msm_get_status");
     const auto t_loop = std::chrono::steady_clock::now();
-    bool aliased_here = false;
+    bool aliased_here = false, mean_skipped_note = false;
     for (;;) {
         bool any_active = false;
         for (int s = 0; s < ns; ++s) any_active = any_active || prev[s].active;
@@ -401,7 +476,9 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
                 return 101;
             }
             if (flags[0] < 0.5) break;
-            if (!any_active) { flush_synth(); continue; }   // idle here, others still stepping: stay in the exchanges
+            // idle here, others still stepping: stay in the exchanges -- and, when every step carries the density
+            // all-reduce, in the steps too (a step without live streams only contributes its zeros to the sum)
+            if (!any_active && !mean_on) { flush_synth(); continue; }
         } else if (!any_active) {
             break;   // main.rs:65: while not_finished()
         }
@@ -443,6 +520,34 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
                 std::printf("Finished %s in %lld seconds\n", streams[s].sim_name.c_str(),
                             (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_loop).count());
         }
+        if (mean_on) {
+            // did this step land EVERY seed stream of EVERY rank on the same dump?  (k here, or -1) -> max and -min
+            int k_here = -1;
+            bool same = true;
+            for (int s = 0; s < ns; ++s) {
+                const bool dumped = st[s].n_steps != prev[s].n_steps && st[s].dump && !st[s].aliased;
+                if (!dumped) { same = false; break; }
+                if (k_here < 0) k_here = st[s].current_dumps;
+                same = same && st[s].current_dumps == k_here;
+            }
+            if (!same) k_here = -1;
+            double kk[2] = {(double)k_here, (double)-k_here};
+            check(ctx, msm_comm_allreduce_f64(ctx, kk, 2, 2), "msm_comm_allreduce_f64");
+            if (kk[0] >= 0 && kk[0] == -kk[1]) {
+                if (lead) {
+                    std::vector<double> mean(n_cells), none;
+                    check(ctx, msm_mean_density(ctx, mean.data(), nullptr), "msm_mean_density");
+                    std::filesystem::create_directories(combined);
+                    char name[64];
+                    std::snprintf(name, sizeof name, "/mean_density_%05d", (int)kk[0]);
+                    writers.submit_task([path = combined + name, data = std::move(mean), shape] { write_npy<double>(path, data.data(), shape); });
+                }
+            } else if (!mean_skipped_note) {
+                mean_skipped_note = true;
+                if (lead) std::printf("(mean density) the streams do not reach their dumps in the same step here: the per-step product is "
+                                      "written only for steps that land every stream on one dump\n");
+            }
+        }
         prev = st;
         flush_synth();
     }
@@ -478,7 +583,14 @@ int run(const Args& args) {
         if (!args.comm_file.empty() && last == first) throw std::runtime_error("--comm-file: more ranks than seed streams");
         if (streams.empty()) { std::printf("rank %d of %d: no streams\n", args.rank, args.world); return 0; }
     }
-    const bool multi_stream = streams.size() > 2;   // SimulationIter::len() counts the seeds (io.rs:121-125)
+    // --mean-density: the context that all-reduces its density every step holds seed streams only; the mean-field run
+    // (last entry, lead rank) follows in a context of its own, outside the communicator
+    std::vector<StreamSpec> mean_field_after;
+    if (args.mean_density) {
+        if (!streams.empty() && !streams.back().sampled) { mean_field_after.push_back(streams.back()); streams.pop_back(); }
+        if (streams.empty()) throw std::runtime_error("--mean-density needs seed streams ([sampling] in the TOML) on every rank");
+    }
+    const bool multi_stream = streams.size() + mean_field_after.size() > 2;   // SimulationIter::len() counts the seeds (io.rs:121-125)
     // The reference runs its simulations one after the other (main.rs:43-79), so any grouping of them is legal: all
     // at once when the device holds them, otherwise in waves of as many as fit (halved until msm_create succeeds).
     size_t wave = streams.size();
@@ -502,6 +614,15 @@ int run(const Args& args) {
         if (rc != 0) return rc;
         w0 = w1;
     }
+    if (!mean_field_after.empty()) {
+        Args alone = args;
+        alone.comm_file.clear();
+        alone.mean_density = alone.synthesize = false;
+        bool nomem = false;
+        const int rc = run_wave<T>(alone, toml, mean_field_after, nomem);
+        if (nomem) throw std::runtime_error(std::string("msm_create failed: ") + msm_last_error(nullptr));
+        if (rc != 0) return rc;
+    }
     if (multi_stream)
         std::printf("Finished all streams in %lld seconds\n",
                     (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count());
@@ -512,10 +633,15 @@ int run(const Args& args) {
 
 int main(int argc, char** argv) {
     const Args args = parse_args(argc, argv);
+    AbortWatch watch(args);
     try {
-        return args.precision == MSM_F64 ? run<double>(args) : run<float>(args);
+        const int rc = args.precision == MSM_F64 ? run<double>(args) : run<float>(args);
+        watch.stop();
+        return rc;
     } catch (const std::exception& e) {
+        watch.stop();
         std::fprintf(stderr, "Error: %s\n", e.what());
+        leave_abort_note(args, e.what());   // the other ranks' watchdogs end them: none stays behind in a collective
         return 1;
     }
 }

@@ -5,8 +5,8 @@ The reference re-reads every stream's every dump from disk, transforms it with a
 un-normalised FFT and averages psi, |psi|^2, psik, |psik|^2 over streams per dump, then
 derives Qx = sum(<|psi|^2> - |<psi>|^2) dv per dump.  Here a stream adds itself to its dump's
 running sums (msm_synth_accumulate) the moment it reaches the dump; when every stream of every
-rank has done so the sums are all-reduced (RCCL through torch.distributed when a process group
-is given), averaged and written in the reference's layout:
+rank has done so the sums are all-reduced (msm_amd.comm: RCCL inside the library, or gloo in CPU
+rehearsals), averaged and written in the reference's layout:
 
     sim-data/{sim_name}-combined/{psi,psi2,psik,psik2}_{dump:05}_{real,imag}   NPY (N,N,N,1) f64
     sim-data/{sim_name}-combined/Qx_{real,imag}                                NPY (n_dumps+1,1,1,1)
@@ -22,13 +22,6 @@ import numpy as np
 FIELDS = ("psi", "psi2", "psik", "psik2")
 
 
-class _DeviceView:
-    """Minimal __cuda_array_interface__ holder so that torch can wrap a raw device pointer."""
-
-    def __init__(self, ptr: int, n_doubles: int):
-        self.__cuda_array_interface__ = {"shape": (n_doubles,), "typestr": "<f8", "data": (ptr, False), "version": 3}
-
-
 def write_complex(path_base: str, arr: np.ndarray):
     """dump_complex (synthesizer/src/lib.rs:72-102): two NPY files without extension, 4-D."""
     os.makedirs(os.path.dirname(path_base), exist_ok=True)
@@ -40,26 +33,21 @@ def write_complex(path_base: str, arr: np.ndarray):
 
 class InSituSynthesizer:
     def __init__(self, ev, sim_name: str, n_streams_global: int, n_dumps: int, out_root: str = ".",
-                 dist=None, write_rank: int = 0, to_tensor=None):
+                 comm=None, write_rank: int = 0, n_cells=None):
         """ev: msm_amd.Evolver (or an object with the same synth_* methods).
         n_streams_global: streams over all ranks; a dump is finalised when that many have arrived.
-        dist: an initialised torch.distributed module for multi-GPU runs, else None.
-        to_tensor(handle, n_doubles): wraps what ev.synth_device returns as a torch tensor
-        (default: device pointer -> CUDA tensor)."""
-        self.ev, self.dist = ev, dist
+        comm: a msm_amd.comm carrier for multi-rank runs (LibraryComm on GPUs), None for one rank.
+        n_cells: cells per grid, needed only by a rank that holds no streams at all (ev is None; gloo rehearsals)."""
+        from .comm import NoComm
+        self.ev, self.comm = ev, comm if comm is not None else NoComm()
         self.base = os.path.join(out_root, "sim-data", f"{sim_name}-combined")
         self.n_global, self.n_dumps = n_streams_global, n_dumps
-        self.rank = dist.get_rank() if dist is not None else 0
+        self.rank = self.comm.rank
         self.write_rank = write_rank
         self.local_counts: Dict[int, int] = {}
         self.qx: Dict[int, complex] = {}
         self.done = set()
-        self._to_tensor = to_tensor or self._device_tensor
-
-    @staticmethod
-    def _device_tensor(ptr, n_doubles):
-        import torch
-        return torch.as_tensor(_DeviceView(ptr, n_doubles), device="cuda")
+        self.n_cells = n_cells
 
     def add(self, stream: int, dump: int):
         """Stream `stream` (local index) has just reached dump `dump`."""
@@ -71,25 +59,20 @@ class InSituSynthesizer:
 
     def finish(self, dump: int):
         """All local streams have contributed to `dump`: reduce over ranks, average, write, free.
-        Collective: every rank must call it for the same dump in the same order."""
+        Collective: every rank must call it for the same dump in the same order (a rank without seed streams too:
+        it contributes zeros)."""
         ev = self.ev
-        handle, count = ev.synth_device(dump)
-        if self.dist is not None:
-            import torch
-            n_doubles = 2 * 4 * int(np.prod(ev.shape))
-            t = self._to_tensor(handle, n_doubles)
-            self.dist.all_reduce(t)                        # sums of the four fields, one message
-            c = torch.tensor([count], dtype=torch.int64, device=t.device)
-            self.dist.all_reduce(c)
-            count = int(c.item())
-            ev.synth_set_count(dump, count)
+        count = self.comm.synth_allreduce(ev, dump, self.n_cells)
         if count != self.n_global:
             raise RuntimeError(f"dump {dump}: {count} streams accumulated, expected {self.n_global}")
-        if self.rank == self.write_rank:
+        if self.rank == self.write_rank and ev is not None:
             for f in FIELDS:
                 write_complex(os.path.join(self.base, f"{f}_{dump:05d}"), ev.synth_fetch(dump, f))
             self.qx[dump] = ev.synth_qx(dump)
-        ev.synth_release(dump)
+        try:
+            ev.synth_release(dump)
+        except Exception:
+            pass                                            # a rank that never opened the slot (or holds no context)
         self.done.add(dump)
         self.local_counts.pop(dump, None)
 

@@ -99,42 +99,39 @@ def test_products_two_pass_engine_256():
 _DIST_SCRIPT = r"""
 import os, sys
 import numpy as np
-import torch                      # first: libmsm_hip.so must bind to the HIP runtime torch already loaded
-import torch.distributed as dist
 root = sys.argv[1]
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
 import sp_oracle as o
 from msm_amd import Evolver
+from msm_amd.comm import LibraryComm
 from msm_amd.synth import FIELDS, InSituSynthesizer
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3])
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 N, ns = 32, 2
 base = dict(axis_length=60.0, final_sim_time=2000.0, cfl=0.1, num_data_dumps=4, total_mass=3e16, hbar_=0.01,
             ntot=1e10, k2_cutoff=0.95, alias_threshold=0.001)
-with Evolver(size=N, n_streams=ns, hip_stream=torch.cuda.current_stream().cuda_stream or None, **base) as ev:
+with Evolver(size=N, n_streams=ns, **base) as ev:
     ev.set_psi(0, o.plane_wave_ics(N)); ev.copy_psi(1, 0)
     for s in range(ns):
         ev.sample(s, "Wigner", 5 + s)
     ev.update()
     psis = [ev.get_psi(s) for s in range(ns)]
-    syn = InSituSynthesizer(ev, "d", ns, 4, out_root=sys.argv[2], dist=dist)
+    comm = LibraryComm(ev, 0, 1, lambda cid: cid)      # a communicator of one: RCCL inside the library
+    assert comm.allreduce([2.5, -1.0], 2) == [2.5, -1.0]
+    syn = InSituSynthesizer(ev, "d", ns, 4, out_root=sys.argv[2], comm=comm)
     for s in range(ns):
         syn.add(s, 1)
-    syn.finish(1)                 # wraps the device sums as a torch tensor and all-reduces them over RCCL
+    syn.finish(1)                 # msm_synth_allreduce: the device sums and the stream count over RCCL, in place
     syn.close()
 want = o.reference_synthesis(psis, (60.0 / N) ** 3)
 for f in FIELDS:
     b = os.path.join(sys.argv[2], "sim-data", "d-combined", f"{f}_00001")
     got = np.load(open(b + "_real", "rb"))[..., 0] + 1j * np.load(open(b + "_imag", "rb"))[..., 0]
     assert np.max(np.abs(got - want[f])) < 1e-12 * np.max(np.abs(want[f])), f
-dist.destroy_process_group()
 print("SYNTH_DIST_OK")
 """
 
 
 def test_reduction_path_over_rccl(tmp_path):
-    """finish() with a process group: the device sums go through torch.distributed (RCCL) in place."""
+    """finish() with the library's communicator: the device sums go through RCCL in place (msm_synth_allreduce)."""
     import socket
     import subprocess
     import sys
@@ -189,7 +186,7 @@ scheme = "Husimi"
         port = s.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "-m", "msm_amd.run", "--toml", str(toml), "--synthesize", "--backend", "gloo"],
+                        "--master-port", str(port), "-m", "msm_amd.run", "--toml", str(toml), "--synthesize", "--backend", "gloo", "--share-gpu"],
                        cwd=two, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     names = [f"spherical-tophat-stream{k:05d}" for k in (1, 2, 3)]

@@ -117,8 +117,9 @@ def _synth_worker(rank, world, port, n_streams, N, root_dir):
     rng = np.random.default_rng(0)
     allpsi = [rng.standard_normal((N, N, N)) + 1j * rng.standard_normal((N, N, N)) for _ in range(n_streams)]
     ev = _FakeSynthEvolver(allpsi[first:first + count], N)
-    syn = InSituSynthesizer(ev, "run", n_streams, 1, out_root=root_dir, dist=dist,
-                            to_tensor=lambda arr, n: torch.from_numpy(arr.view(np.float64)))
+    from msm_amd.comm import GlooComm
+    syn = InSituSynthesizer(ev, "run", n_streams, 1, out_root=root_dir,
+                            comm=GlooComm(dist, to_tensor=lambda arr, n: torch.from_numpy(arr.view(np.float64))))
     for dump in (0, 1):
         for s in range(count):
             syn.add(s, dump)
