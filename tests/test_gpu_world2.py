@@ -65,9 +65,12 @@ def test_library_collectives_two_ranks(tmp_path):
                 assert np.allclose(r["means"][i], want, rtol=1e-11, atol=0), i
         assert np.array_equal(r0["means"], r1["means"])
         psi = np.concatenate([r0["psi"], r1["psi"]])
+        # a stream does not care which context holds it -- to rounding: its Poisson solve shares a complex transform
+        # with whichever stream it is paired with
         for s in range(total):
-            assert np.array_equal(psi[s], ev.get_psi(s)), s            # a stream does not care which context holds it
-        assert np.array_equal(np.concatenate([r0["dt"], r1["dt"]]), np.array([r.dt for r in ev.status()]))
+            want = ev.get_psi(s)
+            assert np.max(np.abs(psi[s] - want)) < 1e-12 * np.max(np.abs(want)), s
+        assert np.allclose(np.concatenate([r0["dt"], r1["dt"]]), np.array([r.dt for r in ev.status()]), rtol=1e-12, atol=0)
         for s in range(total):
             ev.synth_accumulate(s, 3)
         for f in ("psi", "psi2", "psik2"):
