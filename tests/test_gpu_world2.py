@@ -96,6 +96,24 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert r.stderr.count("bench.py rank ") == 2 and "fake_rccl" in r.stderr     # one diagnostic line per rank
 
 
+def test_bench_two_ranks_under_torchrun(tmp_path):
+    """The same through the launcher the round-end driver uses (python -m torch.distributed.run ... bench.py --gpus N):
+    the agent hosts the store, every rank is its client."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--streams", "5",
+                        "--batch", "2", "--steps", "2", "--warmup", "1"], env=fake_env(MSM_BENCH_SHARE_GPU="1"), cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["streams_per_gpu"] == 3 and d["value"] > 0      # ragged: 3 + 2
+
+
 def _toml(tmp_path, name, **over):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_cli import TOPHAT, toml_text
