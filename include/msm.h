@@ -180,7 +180,10 @@ int32_t msm_density_sum(msm_ctx* ctx, void* device_out_f64);
 /* Fast path of the same product: register a DEVICE buffer of N^dims doubles (NULL to stop);
  * every following step zeroes it and leaves in it the sum of |psi_s(t + dt)|^2 over the
  * streams that took the step (one that aliased in it is left out), accumulated inside the step's last pass at no extra HBM read (3-D
- * power-of-two grids; the other grids add one read of the batch). */
+ * power-of-two grids; the other grids add one read of the batch).  Precision: the sum is formed in double from each
+ * stream's components widened to double -- except in the single-precision 512^3 tiling, where a stream's |psi|^2
+ * crosses memory as a single-precision grid first, so every term carries a relative rounding error of about 6e-8
+ * before it is added in double (the same holds for msm_mean_density there). */
 int32_t msm_step_density(msm_ctx* ctx, void* device_out_f64);
 
 /* In-situ synthesizer (synthesizer/src/main.rs:63-93,161-187; lib.rs:190-300): the per-dump
