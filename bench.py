@@ -171,9 +171,12 @@ max_dloga = 0.01
 # bytes one launch of a pass kind reads + writes per stream-cell, by engine (double precision; halve for single):
 #   two-pass tilings of 128^3 and 256^3 = KINDS_TWO_PASS, generic engine = KINDS, and the 512^3 single-precision
 #   tiling, where |psi|^2 and phi cross memory as real grids (given in single-precision bytes)
-KINDS_TILING_512_F32 = {"psi_inv_z": 16.0, "psi_invx_rho": 20.0, "poisson_z": 8.0, "phi_inv_x": 6.0, "psi_fwd_x": 20.0,
+#   psi_invx_rho there = the first stream of a pair (8 in, 4 out) + the second, which packs the pair (8 + 4 in, 8 out per
+#   pair): 16 per stream-cell; phi_inv_x = the pass that stores phi for the kick (4 in, 4 out) and the one that only
+#   takes max|phi| (4 in): 6 on average
+KINDS_TILING_512_F32 = {"psi_inv_z": 16.0, "psi_invx_rho": 16.0, "poisson_z": 8.0, "phi_inv_x": 6.0, "psi_fwd_x": 20.0,
                         "psi_fwdz_invz": 16.0, "rho_fwd_x": 12.0, "plain": 16.0}
-MOVED_512_F32 = 120.0
+MOVED_512_F32 = 112.0     # 16 + 16 + 8 + 8 + 20 + 16 + 16 + 8 + 4
 
 
 def run_config(name, workload, toml_text, size, streams, batch, precision, expanding, scheme, steps, warmup,
