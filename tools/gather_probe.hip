@@ -18,6 +18,53 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr size_t T_ZH = 8, T_B = 128 * T_ZH, T_KXH = 32 * T_B, T_TP = 256 * T_KXH;   // in complex64 elements (8 B)
 constexpr size_t GRID = 512ul * 512 * 512;
 
+// 32-byte pieces: the layout T2[t'][kx][b][z] a tiling with pass-B runs of 2^14 points would have (a run = one kx: a
+// contiguous 128 KB block; an A tile's piece = its four z of one kx).  Four tiles (a z quad of quads) share a 128-byte
+// line and take neighbouring slots of one XCD.  WRITE = 1 stores instead of loading.
+template <int WRITE, int PIECE64>
+__global__ __launch_bounds__(512) void k_piece(float2* __restrict__ T, float* __restrict__ out, int ntiles_total) {
+    __shared__ char pad[140 * 1024];
+    if (threadIdx.x == 0 && ntiles_total < 0) pad[0] = 1;
+    const int tid = threadIdx.x;
+    const int id = blockIdx.x & 4095, stream = blockIdx.x >> 12;
+    const int xcd = id & 7, slot = id >> 3;
+    float2* base = T + (size_t)stream * GRID;
+    f4 v[32];
+    size_t off, kstride = T_TP;
+    int second;                      // offset of the thread's second 16-byte access, in f4 units
+    if (PIECE64) {                   // today's layout, two lanes per 64-byte piece
+        const int group = ((slot >> 1) << 3) | xcd;
+        const int zh = ((group & 63) << 1) | (slot & 1), b = group >> 6, kxh = tid >> 1;
+        off = (size_t)kxh * T_KXH + b * T_B + (size_t)((zh + 4 * kxh) & 127) * T_ZH + 2 * (tid & 1);
+        second = 2;
+    } else {                         // T2: one lane per 32-byte piece
+        const int group = ((slot >> 2) << 3) | xcd;
+        const int zh = ((group & 31) << 2) | (slot & 3), b = group >> 5;
+        off = (size_t)tid * (32 * 512) + (size_t)b * 512 + (size_t)((4 * zh + 16 * tid) & 511);   // (z rotated per kx)
+        second = 1;
+    }
+    if (WRITE) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            f4 d = {(float)tid, (float)k, 1.0f, 2.0f};
+            f4* p = (f4*)(base + off + (size_t)k * kstride);
+            p[0] = d;
+            p[second] = d;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const f4* p = (const f4*)(base + off + (size_t)k * kstride);
+            v[2 * k] = p[0];
+            v[2 * k + 1] = p[second];
+        }
+        f4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc += v[i];
+        if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(512) void k_gather(const float2* __restrict__ T, float* __restrict__ out, int ntiles_total) {
     __shared__ char pad[140 * 1024];
@@ -91,6 +138,22 @@ int main(int argc, char** argv) {
         }
         const double useful = (double)GRID * 8 * streams;
         printf("variant %d: %.3f ms  %.2f TB/s of tile bytes%s\n", v, best, useful / best / 1e9, v == 2 ? " (moves twice that)" : "");
+    }
+    const char* names[4] = {"read 64-B pieces (today)", "read 32-B pieces (T2)", "write 64-B pieces (today)", "write 32-B pieces (T2)"};
+    for (int v = 0; v < 4; ++v) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            CHECK(hipEventRecord(e0));
+            if (v == 0) k_piece<0, 1><<<4096 * streams, 512>>>(T, out, 4096 * streams);
+            else if (v == 1) k_piece<0, 0><<<4096 * streams, 512>>>(T, out, 4096 * streams);
+            else if (v == 2) k_piece<1, 1><<<4096 * streams, 512>>>(T, out, 4096 * streams);
+            else k_piece<1, 0><<<4096 * streams, 512>>>(T, out, 4096 * streams);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        printf("%s: %.3f ms  %.2f TB/s of tile bytes\n", names[v], best, (double)GRID * 8 * streams / best / 1e9);
     }
     CHECK(hipGetLastError());
     return 0;
