@@ -130,6 +130,11 @@ __device__ __forceinline__ void absmax_acc(double& m, bool& bad, double v) {
     bad |= (v != v);
 }
 __device__ __forceinline__ double absmax_done(double m, bool bad) { return bad ? __builtin_nan("") : m; }
+// (single precision: the maximum of magnitudes is exact in the values' own type; it is widened once, by absmax_done)
+__device__ __forceinline__ void absmax_acc(float& m, bool& bad, float v) {
+    m = __builtin_fmaxf(m, __builtin_fabsf(v));
+    bad |= (v != v);
+}
 
 // Workgroup reductions in a fixed order (bitwise reproducible from run to run): whole wavefronts reduce by
 // lane exchange and meet in one LDS round, smaller workgroups walk an LDS tree.  The barriers order LDS traffic only,
