@@ -150,18 +150,22 @@ def test_cli_mean_density_world_1(tmp_path):
     assert np.max(np.abs(_load(tmp_path, "md1", "psi", 3) - mft.psi)) < 1e-11 * np.max(np.abs(mft.psi))
 
 
-def test_cli_two_ranks_match_one(tmp_path):
+@pytest.mark.parametrize("expanding", [False, True], ids=["static", "expanding"])
+def test_cli_two_ranks_match_one(tmp_path, expanding):
     """msm-simulator --rank r --world 2 --comm-file ... --synthesize --mean-density on one GPU against the same TOML
-    run by one process: identical dumps, ensemble products equal to rounding of the sums' order."""
+    run by one process: identical dumps, ensemble products equal to rounding of the sums' order (static and expanding
+    boxes: the expanding loop keeps its host scale-factor state per rank)."""
     one, two = tmp_path / "one", tmp_path / "two"
     one.mkdir()
     two.mkdir()
-    cfg, path = _toml(tmp_path, "w2")
-    r = subprocess.run([BIN, "--toml", str(path), "--synthesize", "--mean-density", "--comm-file", str(one / "c.id")],
+    over = dict(cosmology=dict(omega_matter_now=0.7, omega_radiation_now=0.0, h=0.7, z0=1.0, max_dloga=0.01)) if expanding else {}
+    cfg, path = _toml(tmp_path, "w2", **over)
+    flags = ["--expanding"] if expanding else []
+    r = subprocess.run([BIN, "--toml", str(path), "--synthesize", "--mean-density", "--comm-file", str(one / "c.id"), *flags],
                        cwd=one, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     outs = run_ranks([[BIN, "--toml", str(path), "--synthesize", "--mean-density", "--rank", str(rk), "--world", "2",
-                       "--comm-file", str(two / "c.id")] for rk in range(2)], fake_env(), str(two))
+                       "--comm-file", str(two / "c.id"), *flags] for rk in range(2)], fake_env(), str(two))
     for rc, so, se in outs:
         assert rc == 0, (rc, so[-1500:], se[-1500:])
     for sim in ("w2", "w2-stream00001", "w2-stream00002", "w2-stream00003"):
