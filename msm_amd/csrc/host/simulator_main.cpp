@@ -27,7 +27,8 @@
 //   as sim-data/{sim_name}-combined/mean_density_{k:05} (one real NPY array).  The mean-field run is evolved after
 //   the seed streams, in a context of its own (the synthesizer leaves it out, lib.rs:190-193).
 // A rank that fails leaves a note in PATH.abort; a watchdog thread in every other rank sees it and ends that rank with a
-//   non-zero status, also when it is blocked inside a collective.
+//   non-zero status, also when it is blocked inside a collective.  (PATH must be new for every launch: a PATH.abort left
+//   by an earlier launch ends the next one at once, with the old note in the message.)
 #include <algorithm>
 #include <atomic>
 #include <chrono>
