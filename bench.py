@@ -357,6 +357,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rank 0's stdout carries ONE line, the JSON.  Libraries write there too (RCCL prints a version banner when a
+    # communicator is formed), so from here on file descriptor 1 is stderr, and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must equal --gpus")
     N = args.size
@@ -498,7 +503,7 @@ def main():
             out["extra_configs"] = extra_configs(None if wanted is None else wanted - {"headline"}, args.extra_budget_s)
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(N)
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     ev.close()
 

@@ -88,12 +88,27 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
                         "--steps", "3", "--warmup", "1"], env=fake_env(MSM_BENCH_SHARE_GPU="1"), cwd=str(tmp_path),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["density_allreduce"] is True and d["config"]["streams_per_gpu"] == 3
     assert d["value"] > 0 and "extra_configs" not in d and "cpu_baseline" not in d
     assert r.stderr.count("bench.py rank ") == 2 and "fake_rccl" in r.stderr     # one diagnostic line per rank
+
+
+def test_bench_real_rccl_world_1_prints_one_line(tmp_path):
+    """bench.py's multi-rank path through the REAL librccl with a communicator of one (MSM_BENCH_FORCE_DIST): RCCL writes
+    a version banner to the process's stdout when a communicator is formed; rank 0's stdout must still carry exactly
+    one line, the JSON."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--streams", "4", "--batch", "2", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], env=dict(os.environ, MSM_BENCH_FORCE_DIST="1"), cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["density_allreduce"] is True and d["value"] > 0
+    assert "RCCL from librccl" in r.stderr
 
 
 def test_bench_two_ranks_under_torchrun(tmp_path):
