@@ -252,13 +252,14 @@ def test_512_f32_expanding_step_vs_oracle(two_pass):
         os.environ.pop("MSM_TWO_PASS", None)
 
 
-def _run_512(mode, cosmology):
-    """Three single-precision streams at 512^3 in sub-batches of two (a pair and an unpaired stream), two steps."""
+def _run_512(mode, cosmology, batch=2):
+    """Three single-precision streams at 512^3 in sub-batches of two (a pair and an unpaired stream) or in one sub-batch
+    (a pair and an unpaired stream side by side), two steps."""
     N = 512
     os.environ["MSM_TWO_PASS"] = str(mode)
     try:
         base = dict(TOPHAT, cfl=0.05)
-        with Evolver(size=N, n_streams=3, batch_streams=2, cosmology=cosmology, precision="f32", **base) as ev:
+        with Evolver(size=N, n_streams=3, batch_streams=batch, cosmology=cosmology, precision="f32", **base) as ev:
             assert ev.derived()["transform_passes_mode"] == float(mode)
             rng = np.random.default_rng(7)
             for s in range(3):
@@ -285,12 +286,14 @@ def _run_512(mode, cosmology):
         os.environ.pop("MSM_TWO_PASS", None)
 
 
-@pytest.mark.parametrize("cosmology", [None, COSMO], ids=["static", "expanding"])
-def test_two_pass_engine_matches_three_pass_512_f32(cosmology):
+@pytest.mark.parametrize("cosmology,batch", [(None, 2), (COSMO, 2), (None, 4)], ids=["static", "expanding", "static-one-batch"])
+def test_two_pass_engine_matches_three_pass_512_f32(cosmology, batch):
     """The single-precision 512^3 tiling (two passes per transform) against the generic engine (three passes), which the
-    oracle tests pin at every size: same steps and flags, fields equal to single-precision rounding."""
-    r3, psi3, psik3, phi3 = _run_512(0, cosmology)
-    r2, psi2, psik2, phi2 = _run_512(2, cosmology)
+    oracle tests pin at every size: same steps and flags, fields equal to single-precision rounding.  The sub-batch
+    shapes cover every way the tiling forms its densities: a whole pair (packed in registers by the second stream's
+    pass), an unpaired stream alone, and an unpaired stream behind a pair in one launch."""
+    r3, psi3, psik3, phi3 = _run_512(0, cosmology, batch)
+    r2, psi2, psik2, phi2 = _run_512(2, cosmology, batch)
     for a, b in zip(r3, r2):
         for x, y in zip(a, b):
             assert x[4:] == y[4:]
