@@ -536,7 +536,7 @@ int run_wave(const Args& args, const TomlParameters& toml, const std::vector<Str
             check(ctx, msm_comm_allreduce_f64(ctx, kk, 2, 2), "msm_comm_allreduce_f64");
             if (kk[0] >= 0 && kk[0] == -kk[1]) {
                 if (lead) {
-                    std::vector<double> mean(n_cells), none;
+                    std::vector<double> mean(n_cells);
                     check(ctx, msm_mean_density(ctx, mean.data(), nullptr), "msm_mean_density");
                     std::filesystem::create_directories(combined);
                     char name[64];
