@@ -23,6 +23,8 @@ PMC counters saw it move.  The whole-step figures `step_frac*` use the reference
 
 With one GPU the same line also carries `extra_configs`: the other single-GPU configurations of the benchmark list,
 each run after the headline context has been closed, with its own timed steps and HIP-event pass timings --
+  c1_512_f64_mft                      examples/gaussian-overdensity-mft.toml as shipped (size 512, fp64, the mean-field
+                                      stream alone): the reference's own example at the precision its binary runs
   c2_128_1stream / c2_128_64streams   examples/spherical-tophat.toml at size 128, fp64, static box
   c3_256_64streams                    tomls/planeWave3d_e10_sym.toml at size 256, 64 Wigner streams in sub-batches of 32
   c5_512_f32_expanding_64streams      examples/spherical-tophat-cosmo.toml at size 512, fp32, expanding box, the 64
@@ -281,7 +283,13 @@ def extra_configs(wanted, budget_s):
     plane_toml = ('axis_length = 60.0\nfinal_sim_time = 2000\ncfl = 0.1\nnum_data_dumps = 64\ntotal_mass = 3e16\nhbar_ = 0.01\n'
                   'ntot = 1e10\nsim_name = "planeWave3d_e10_sym"\nk2_cutoff = 0.95\nalias_threshold = 0.001\ndims = 3\nsize = 256\n'
                   '[ics]\ntype = "UserSpecified"\npath = "regenerated-at-size-256"\n' + sampled(64, "Wigner"))
+    gauss_toml = ('axis_length = 30\nfinal_sim_time = 400\ncfl = 0.02\nnum_data_dumps = 200\ntotal_mass = 1e10\nhbar_ = 0.02\n'
+                  'sim_name = "gaussian-overdensity-512-mft"\nk2_cutoff = 0.95\nalias_threshold = 0.02\ndims = 3\nsize = 512\n'
+                  '[ics]\ntype = "ColdGauss"\nmean = [15, 15, 15]\nstd = [10, 10, 10]\n')
     specs = {
+        "c1_512_f64_mft": lambda: run_config(
+            "c1_512_f64_mft", "examples/gaussian-overdensity-mft.toml as shipped: size 512, fp64, mean-field stream only, static box",
+            gauss_toml, 512, 1, 0, "f64", False, None, steps=20, warmup=2),
         "c2_128_1stream": lambda: run_config(
             "c2_128_1stream", "examples/spherical-tophat.toml, size 128, fp64, mean-field stream only, static box",
             TOPHAT_TOML.format(name="spherical-tophat", size=128, sampling="", cosmology=""), 128, 1, 0, "f64", False, None,
@@ -345,9 +353,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--streams", type=int, default=256, help="total streams over all GPUs")
-    ap.add_argument("--batch", type=int, default=128, help="streams per kernel launch (sub-batch)")
+    ap.add_argument("--batch", type=int, default=256, help="streams per kernel launch (sub-batch); halved while the batch "
+                                                            "buffers do not fit the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--configs", default="all", help="all | comma list of headline, c2, c3, c5 (extras run with one GPU only)")
+    ap.add_argument("--configs", default="all", help="all | comma list of headline, c1, c2, c3, c5 (extras run with one GPU only)")
     ap.add_argument("--extra-budget-s", type=float, default=200.0, help="wall-time bound of the extra configurations")
     args = ap.parse_args()
 
@@ -392,7 +401,17 @@ def main():
     first, n_local = partition_streams(args.streams, world, rank)
     seeds = [first + 1 + i for i in range(n_local)]
 
-    ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank, **PLANE)
+    # All local streams in one launch per kernel when the batch buffers fit beside the states (256 streams: 64 GiB of
+    # states + 128 GiB of batch buffers); otherwise halve the sub-batch.
+    args.batch = max(1, min(args.batch, n_local))
+    while True:
+        try:
+            ev = msm_amd.Evolver(size=N, n_streams=n_local, batch_streams=args.batch, device=local_rank, **PLANE)
+            break
+        except msm_amd.MsmError as e:
+            if not any(k in str(e).lower() for k in ("device memory", "out of memory")) or args.batch <= 32:
+                raise
+            args.batch //= 2
     if use_dist:
         key = "msm_bench_comm_id/" + os.environ.get("TORCHELASTIC_RUN_ID", "self") + "/" + \
               os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")

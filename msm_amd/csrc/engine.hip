@@ -878,6 +878,15 @@ int Engine::init(std::string& err) {
     HIP_TRY(hipMemcpy(st_.nsteps, zl.data(), sizeof(long long) * ns_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(st_.drift, one_c.data(), sizeof(cplx) * (size_t)ns_ * N_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(P_, 0, grid_bytes * ns_));
+    if (const char* e = getenv("MSM_POISON"); e && atoi(e) != 0) {
+        // diagnostic: the work arrays start as NaN bit patterns, so a read of memory that no kernel has written shows
+        // in the results instead of depending on what the allocation held before
+        HIP_TRY(hipMemset(X_, 0xFF, grid_bytes * (size_t)(2 * pairs)));
+        HIP_TRY(hipMemset(W_, 0xFF, grid_bytes * (lowdim_ ? 2 * pairs : pairs)));
+        HIP_TRY(hipMemset(stage_, 0xFF, grid_bytes));
+        HIP_TRY(hipMemset(PHI_, 0xFF, n3_ * sizeof(real) * (size_t)(2 * pairs)));
+        HIP_TRY(hipMemset(partial_, 0xFF, sizeof(double) * (size_t)ns_ * ntiles_));
+    }
     host_active_.assign(ns_, 1);
     publish();
     HIP_TRY(hipStreamSynchronize(stream_));

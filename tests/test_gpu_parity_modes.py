@@ -252,6 +252,35 @@ def test_512_f32_expanding_step_vs_oracle(two_pass):
         os.environ.pop("MSM_TWO_PASS", None)
 
 
+def test_512_f64_mean_field_example_step_vs_oracle():
+    """examples/gaussian-overdensity-mft.toml as shipped -- size 512, double precision (the reference binary's
+    `type T = f64`, simulator/src/main.rs:19), ColdGauss ICs, the mean-field stream alone -- two steps on the generic
+    three-pass engine against the numpy oracle: dt, max|phi|, time, alias mass, psi and psi_k."""
+    N = 512
+    o.FFT_WORKERS = 16
+    try:
+        base = dict(axis_length=30.0, final_sim_time=400.0, cfl=0.02, num_data_dumps=200, total_mass=1e10, hbar_=0.02,
+                    k2_cutoff=0.95, alias_threshold=0.02)
+        toml = dict(base, sim_name="gaussian-overdensity-512-mft", dims=3, size=N,
+                    ics=dict(type="ColdGauss", mean=[15.0, 15.0, 15.0], std=[10.0, 10.0, 10.0]))
+        sim = o.SimulationObject(list(o.simulation_iter(toml))[-1])
+        with Evolver(size=N, n_streams=1, **base) as ev:
+            assert ev.derived()["transform_passes_mode"] == 0.0          # the generic engine
+            ev.set_psi(0, sim.psi)
+            for i in range(2):
+                ev.update()
+                info = sim.update()
+                st = ev.status()[0]
+                assert abs(st.dt / float(info["dt"]) - 1) <= 1e-12 and bool(st.dump) == info["dump"], (i, st.dt, info["dt"])
+                assert abs(st.time / float(info["time"]) - 1) <= 1e-12 and st.aliased == 0
+                assert abs(st.max_phi / float(info["max_phi"]) - 1) <= 1e-11
+                assert abs(st.alias_mass - float(info["alias_mass"])) <= 1e-9 * max(float(info["alias_mass"]), 1e-30) + 1e-25
+            assert rel_err(ev.get_psi(0), sim.psi) < 1e-11
+            assert rel_err(ev.get_psik(0), sim.psik) < 1e-11
+    finally:
+        o.FFT_WORKERS = 0
+
+
 def _run_512(mode, cosmology, batch=2):
     """Three single-precision streams at 512^3 in sub-batches of two (a pair and an unpaired stream) or in one sub-batch
     (a pair and an unpaired stream side by side), two steps."""
@@ -299,8 +328,15 @@ def test_two_pass_engine_matches_three_pass_512_f32(cosmology, batch):
             assert x[4:] == y[4:]
             assert abs(x[0] / y[0] - 1) < 2e-5 and abs(x[1] / y[1] - 1) < 2e-5
             assert abs(x[2] / y[2] - 1) < 5e-3          # max|phi| of a nearly uniform density is ill-conditioned
-    for s in range(3):
-        assert rel_err(psi2[s], psi3[s]) < 2e-5, s
+    errs = [rel_err(psi2[s], psi3[s]) for s in range(3)]
+    if max(errs) >= 2e-5:
+        # say which engine moved: each is bitwise reproducible, so a second run of both names the one that is not
+        _, psi3b, _, _ = _run_512(0, cosmology, batch)
+        _, psi2b, _, _ = _run_512(2, cosmology, batch)
+        again3 = [float(np.max(np.abs(psi3b[s] - psi3[s]))) for s in range(3)]
+        again2 = [float(np.max(np.abs(psi2b[s] - psi2[s]))) for s in range(3)]
+        raise AssertionError(f"engines differ by {errs}; three-pass engine against its own second run {again3}, "
+                             f"tiling against its own second run {again2}")
     assert rel_err(psik2, psik3) < 2e-5
     for s in range(2):
         assert rel_err(phi2[s], phi3[s]) < 1e-2, s
