@@ -442,15 +442,17 @@ class Engine final : public IEngine {
                     bool scaled = true);
     // dims < 3
     PwArgs pw_args(int s0, const int* act) const;
-    void lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act);
+    void lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act,
+                        bool reduce_max = true);
     void lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau);
     PoisArgs pois_args(int s0, int nb, const int* act) const;
 #ifdef MSM_TQ
     void tq_rho_from_state(const PoisArgs& p, int nb, bool dens);
 #endif
     // W passes after the fused/rho x pass; with_x = false leaves F_y,z-inverted W for a fused consumer
+    // (reduce_max = false leaves max|phi| as per-workgroup maxima: the next step's timestep kernel reduces them)
     void poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x = true, const int* act = nullptr,
-                      bool phi_for_kick = false);
+                      bool phi_for_kick = false, bool reduce_max = true);
     // act = all_active_ solves for finished streams too (standalone msm_potential)
     void poisson_from_psi(const cplx* X, bool local, int s0, int nb, bool store_phi, bool track_max, const int* act);
     // two-pass psi transforms (two_pass_): the kinetic round trip through pass B, psi_k for downloads, and pass A
@@ -989,7 +991,8 @@ void Engine::tq_rho_from_state(const PoisArgs& p, int nb, bool dens) {
 
 // y, z (fused with the Green's multiply), y^-1, x^-1 of the Poisson solve; W already holds F_x[rho]
 // (two-pass layout: W holds T and one pass-B kernel replaces the three middle passes)
-void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x, const int* act, bool phi_for_kick) {
+void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool with_x, const int* act, bool phi_for_kick,
+                          bool reduce_max) {
     if (!act) act = st_.active;
     const int pairs = (nb + 1) / 2;
     PoisArgs p = pois_args(s0, nb, act);
@@ -1023,7 +1026,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
                 else k_phi_max3<<<dim3(tp::A_TILES), block, 0, stream_>>>(p);
             });
         }
-        if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp_a_tiles_, s0, act);
+        if (with_x && track_max && reduce_max) k_reduce_max<<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp_a_tiles_, s0, act);
         if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = phi_for_kick ? 0 : nb; }   // (tile order is not for downloads)
         return;
     }
@@ -1044,7 +1047,7 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
             else k_phi_out<N, 0, 1><<<grid0, block0, 0, stream_>>>(p);
         });
     });
-    if (with_x && track_max) k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tiles_x_, s0, act);
+    if (with_x && track_max && reduce_max) k_reduce_max<<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tiles_x_, s0, act);
     if (with_x && store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
@@ -1150,7 +1153,8 @@ PwArgs Engine::pw_args(int s0, const int* act) const {
 
 // dims < 3: calculate_potential (simulation_object.rs:1066-1110) as the reference spells it: density, transform,
 // Green's multiply, transform back; max|phi| per stream; W (one slot per stream) is left holding phi in its real part.
-void Engine::lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act) {
+void Engine::lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0, int nb, bool store_phi, const int* act,
+                            bool reduce_max) {
     PwArgs a = pw_args(s0, act);
     a.src = psi; a.src_local = local ? 1 : 0; a.scale = psi_scale;
     const dim3 grid(pw_blocks_, (unsigned)nb), block(256);
@@ -1160,7 +1164,7 @@ void Engine::lowdim_poisson(const cplx* psi, bool local, real psi_scale, int s0,
     fft3_plain(W_, true, W_, true, s0, nb, +1, act, false);
     if (store_phi) k_pw_phi<1><<<grid, block, 0, stream_>>>(a);
     else k_pw_phi<0><<<grid, block, 0, stream_>>>(a);
-    k_reduce_partials<1><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, pw_blocks_, s0, act);
+    if (reduce_max) k_reduce_max<<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, pw_blocks_, s0, act);
     if (store_phi) { phi_s0_ = s0; phi_nb_ = nb; }
 }
 
@@ -1173,21 +1177,20 @@ void Engine::lowdim_step_back(int s0, int nb, const real* nt, const real* ntau, 
     k_pw_drift<0><<<grid, block, 0, stream_>>>(a);
     fft3_plain(X_, true, X_, true, s0, nb, +1, st_.active);
     // phi at the half-drifted psi, kick
-    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.active);
+    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.active, false);   // (its max|phi| is not used)
     a.dst = X_; a.scale = (real)1;
     k_pw_kick<<<grid, block, 0, stream_>>>(a);
     // psi_k = D F[psi], aliased mass
     fft3_plain(X_, true, X_, true, s0, nb, -1, st_.active);
     a.src = X_; a.src_local = 1; a.dst = P_; a.dst_local = 0; a.scale = (real)1;
     k_pw_drift<1><<<grid, block, 0, stream_>>>(a);
-    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, pw_blocks_, s0, st_.active);
-    k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+    k_post_step<<<nb, 256, 0, stream_>>>(st_, c_, s0, partial_, ntiles_, pw_blocks_, nt, ntau, stau);
     // potential of psi(t + dt) for the next timestep (:497); the tail also runs for a stream that has just reached
     // the final time, so that its last density is part of msm_step_density's product
     fft3_plain(P_, false, X_, true, s0, nb, +1, st_.stepped);
     if (step_dens_)
         k_density_add_active<<<(unsigned)std::min<size_t>((n3_ + 255) / 256, 2048), 256, 0, stream_>>>(X_, n3_, nb, st_.stepped, s0, step_dens_);
-    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.stepped);
+    lowdim_poisson(X_, true, (real)1, s0, nb, false, st_.stepped, false);   // max|phi| is reduced by the next k_front
 }
 
 // Before the first step P_ holds psi: size the first timestep from it (simulation_object.rs:497)
@@ -1208,14 +1211,17 @@ void Engine::first_step_init(int s0, int nb) {
     }
 }
 
-// timestep (simulation_object.rs:500); max|phi| of psi(t) was left by the previous step's tail
+// timestep (simulation_object.rs:500) from the per-workgroup maxima of |phi| that the previous step's tail (or the
+// first step's set-up, or msm_potential) left; in a static box the kinetic drift table follows in the same launch
 void Engine::step_front(int s0, int nb) {
-    k_timestep<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb);
+    const int nvalid = lowdim_ ? pw_blocks_ : two_pass_ ? tp_a_tiles_ : tiles_x_;
+    if (cfg_.expanding) k_front<0><<<nb, 256, 0, stream_>>>(st_, c_, ksq_, partial_, ntiles_, nvalid, s0);
+    else k_front<1><<<nb, 256, 0, stream_>>>(st_, c_, ksq_, partial_, ntiles_, nvalid, s0);
 }
 
 // drift/2, F^-1, potential, kick, F, drift/2, F^-1, bookkeeping, potential for the next dt (:504-635, :497)
 void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const real* stau) {
-    k_drift_table<<<dim3((N_ + 63) / 64, nb), 64, 0, stream_>>>(st_, c_, ksq_, s0);
+    if (cfg_.expanding) k_drift_table<<<dim3((N_ + 63) / 64, nb), 64, 0, stream_>>>(st_, c_, ksq_, s0);   // else: k_front
     PsiArgs a{};
     a.n3 = n3_; a.active = st_.active; a.s0 = s0; a.pair_nb = 0; a.tw = tw_; a.drift = st_.drift;
     a.phi = PHI_; a.kick = st_.kick; a.scale = (real)1;
@@ -1264,14 +1270,13 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
         // and leaves the new state
         kick();
         psi_rt(S, S, true, s0, nb, st_.active, PK_FWDZ_INVZ);
-        k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tp_b_blocks_, s0, st_.active);
-        k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+        k_post_step<<<nb, 256, 0, stream_>>>(st_, c_, s0, partial_, ntiles_, tp_b_blocks_, nt, ntau, stau);
         // potential of psi(t + dt) straight from the state, for every stream that took the step (one that has
         // just reached the final time included: its last density belongs to msm_step_density's product)
         p.dens = step_dens_;
         p.active = st_.stepped;
         invx_rho(step_dens_ != nullptr);
-        poisson_tail(s0, nb, false, true, true, st_.stepped);
+        poisson_tail(s0, nb, false, true, true, st_.stepped, false, false);   // max|phi| is reduced by the next k_front
         if (tq_) phi_nb_ = 0;   // the rho grids went through the potential array
         return;
     }
@@ -1310,8 +1315,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
             k_fwdz_invz<N><<<dim3((unsigned)(n3_ / N / GS::LPW), (unsigned)nb), dim3(GS::THREADS), 0, stream_>>>(f);
         });
     });
-    k_reduce_partials<0><<<nb, 256, 0, stream_>>>(st_, partial_, ntiles_, tiles_z_, s0, st_.active);
-    k_post_step<<<(nb + 63) / 64, 64, 0, stream_>>>(st_, c_, s0, nb, nt, ntau, stau);
+    k_post_step<<<nb, 256, 0, stream_>>>(st_, c_, s0, partial_, ntiles_, tiles_z_, nt, ntau, stau);
     // streams that took the step: finish psi(t + dt) only as far as the next step needs it,
     // i.e. its density (and the ensemble density if asked for); psi itself is not written back
     a.active = st_.stepped;
@@ -1327,7 +1331,7 @@ void Engine::step_back(int s0, int nb, const real* nt, const real* ntau, const r
             else k_invx_rho<N, 0, 0, 0><<<grid, block, 0, stream_>>>(p);
         });
     });
-    poisson_tail(s0, nb, false, true, true, st_.stepped);
+    poisson_tail(s0, nb, false, true, true, st_.stepped, false, false);   // max|phi| is reduced by the next k_front
 }
 
 int Engine::step(std::string& err) {
