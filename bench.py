@@ -303,10 +303,10 @@ def extra_configs(wanted, budget_s):
             plane_toml, 256, 64, 32, "f64", False, "Wigner", steps=15, warmup=2, psi0=plane_wave_psi(256)),
         "c5_512_f32_expanding_64streams": lambda: run_config(
             "c5_512_f32_expanding_64streams",
-            "examples/spherical-tophat-cosmo.toml, size 512, fp32, expanding box, 64 Husimi streams in sub-batches of 32 "
+            "examples/spherical-tophat-cosmo.toml, size 512, fp32, expanding box, 64 Husimi streams in one launch per kernel "
             "(one GPU's share of 512), host scale-factor loop between msm_step_begin and msm_step_end",
             TOPHAT_TOML.format(name="spherical-tophat-cosmo", size=512, sampling=sampled(64, "Husimi"), cosmology=TOPHAT_COSMOLOGY),
-            512, 64, 32, "f32", True, "Husimi", steps=10, warmup=2),
+            512, 64, 64, "f32", True, "Husimi", steps=10, warmup=2),
     }
     out, t0 = {}, time.perf_counter()
     for name, fn in specs.items():
