@@ -89,16 +89,15 @@ KINDS_TWO_PASS = {
 
 
 # pass kind -> kernel name in the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-# command at 32 and at 128 streams per launch, corrected as profiles/summarize_pmc.py documents)
-PMC_SUMMARY = {32: os.path.join(ROOT, "profiles", "r03_pmc_traffic_32streams.json"),
-               128: os.path.join(ROOT, "profiles", "r03_pmc_traffic_128streams.json")}
+# command at 32, 128 and 256 streams per launch, corrected as profiles/summarize_pmc.py documents)
+PMC_SUMMARY = {n: os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{n}streams.json") for n in (32, 128, 256)}
 PMC_KERNEL = {"psi_inv_z": "k_psi_rt<0>", "psi_invx_rho": "k_invx_rho3<0>", "poisson_z": "k_poisson_b",
               "psi_fwd_x": "k_kick3", "psi_fwdz_invz": "k_psi_rt<1>", "phi_inv_x": "k_phi_max3"}
 
 
 def measured_traffic(kind, two_pass, cells_per_launch, n3):
     """(HBM bytes per launch of the dominant kernel from the PMC counters, note).  The bytes are reported only when a
-    committed summary covers this launch shape (two-pass engine, 32 or 128 x 256^3 cells per launch) AND was taken
+    committed summary covers this launch shape (two-pass engine, 32, 128 or 256 x 256^3 cells per launch) AND was taken
     from the device sources this run's library was built from (the summary's `_meta.kernel_source_hash`)."""
     per_launch = cells_per_launch // n3
     if not two_pass or cells_per_launch != per_launch * n3 or per_launch not in PMC_SUMMARY or n3 != 256 ** 3 \
@@ -131,7 +130,7 @@ def cpu_baseline(size, seconds_cap=30.0):
     sim.update()  # warm-up; includes the one-off psi_k = F psi
     t0 = time.perf_counter()
     steps = 0
-    while steps < 20 and time.perf_counter() - t0 < seconds_cap / 2:
+    while steps < 60 and time.perf_counter() - t0 < seconds_cap / 2:      # about 15 s of CPU work
         sim.update()
         steps += 1
     dt = time.perf_counter() - t0
