@@ -504,6 +504,10 @@ def main():
                         # stricter model: the four Poisson transforms counted as real-data transforms (168 B per update)
                         step_frac_real_poisson=round(value * 168.0 / world / 1e9 / HBM_PEAK_GBS, 4),
                         per_kind_ms={k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
+                        # every pass kind's own algorithmic bytes over its average launch time (GB/s), and launches per step
+                        per_kind_gbs={k: round((KINDS_TWO_PASS if two_pass else KINDS)[k][1] * cells_per_launch
+                                               / (v[0] / max(v[1], 1) / 1e3) / 1e9, 1) for k, v in prof.items()},
+                        per_kind_launches_per_step={k: round(v[1] / args.steps, 2) for k, v in prof.items()},
                         passes_per_transform=2 if two_pass else 3)
         out = {
             "metric": "stream-cell updates/sec (N^3*N_streams/step) at 256^3x256; % HBM roofline",
