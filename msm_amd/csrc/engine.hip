@@ -976,9 +976,12 @@ PoisArgs Engine::pois_args(int s0, int nb, const int* act) const {
 // every pair leaves |psi_a|^2 as a real grid (in the potential array), the second stream's workgroups read it and pack
 // the pair in registers; an unpaired last stream goes through k5_rho_fwd.  With `dens` every stream's |psi|^2 is kept
 // as a grid and summed into the ensemble density of the streams in p.active.
+// Launch rows of the 512^3 pass-A kernels that walk their tile through several streams (k5_inv_rho, k5_phi_out): two rows
+// share the streams of a batch, so that a workgroup has a next tile to request while it finishes the current one.
+static unsigned tq_rows(int count) { return (unsigned)std::min(count, 2); }
 void Engine::tq_rho_from_state(const PoisArgs& p, int nb, bool dens) {
     const dim3 block(tq::THREADS);
-    k5_inv_rho<2><<<dim3(tq::A_TILES, (unsigned)((nb + 1) / 2)), block, 0, stream_>>>(p);
+    k5_inv_rho<2><<<dim3(tq::A_TILES, tq_rows((nb + 1) / 2)), block, 0, stream_>>>(p);
     if (nb >= 2) {
         const dim3 grid(tq::A_TILES, (unsigned)(nb / 2));
         if (dens) k5_inv_rho_pack<1><<<grid, block, 0, stream_>>>(p);
@@ -996,14 +999,15 @@ void Engine::poisson_tail(int s0, int nb, bool store_phi, bool track_max, bool w
     if (!act) act = st_.active;
     const int pairs = (nb + 1) / 2;
     PoisArgs p = pois_args(s0, nb, act);
-    p.phi_tiled = phi_for_kick ? 1 : 0;
     if (two_pass_) {
 #ifdef MSM_TQ
         if (tq_) {
             timed(PK_POISSON_Z, [&] { k5_poisson_b<<<dim3(tq::B_BLOCKS, (unsigned)pairs), dim3(tq::THREADS), 0, stream_>>>(p); });
-            const dim3 grid(tq::A_TILES, (unsigned)pairs), block(tq::THREADS);
+            const dim3 grid(tq::A_TILES, tq_rows(pairs)), block(tq::THREADS);
             if (with_x) timed(PK_PHI_X, [&] {
-                if (store_phi && track_max) k5_phi_out<1, 1><<<grid, block, 0, stream_>>>(p);
+                if (store_phi && phi_for_kick && track_max) k5_phi_out<2, 1><<<grid, block, 0, stream_>>>(p);
+                else if (store_phi && phi_for_kick) k5_phi_out<2, 0><<<grid, block, 0, stream_>>>(p);
+                else if (store_phi && track_max) k5_phi_out<1, 1><<<grid, block, 0, stream_>>>(p);
                 else if (store_phi) k5_phi_out<1, 0><<<grid, block, 0, stream_>>>(p);
                 else k5_phi_out<0, 1><<<grid, block, 0, stream_>>>(p);
             });
