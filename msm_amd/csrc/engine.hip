@@ -180,7 +180,10 @@ __device__ __forceinline__ double recip_t(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
-__device__ __forceinline__ float recip_t(float x) { return 1.0f / x; }
+__device__ __forceinline__ float recip_t(float x) {      // the same in single precision (the IEEE division expands to a dozen instructions)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
 
 // Hides a lane offset from common-subexpression elimination: addresses formed from the result are
 // rebuilt where they are used instead of being kept (or spilled) since their first use.
