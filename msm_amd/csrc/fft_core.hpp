@@ -48,21 +48,24 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
     return unpk2(va * bx + sw * by);
 }
 __device__ __forceinline__ float2 cscale(float2 a, float s) { const f32pair sv = {s, s}; return unpk2(pk2(a) * sv); }
-// e + i o = (e.x - o.y, e.y + o.x) and e - i o = (e.x + o.y, e.y - o.x): one packed add each, the component swap of o
-// and the sign riding along as operand modifiers (written as `e + {-o.y, o.x}` the compiler builds the rotated pair
-// first, one v_xor and one v_mov per butterfly -- a tenth of the instructions of a single-precision transform kernel).
-__device__ __forceinline__ float2 cadd_i(float2 e, float2 o) {
-    f32pair r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(r) : "v"(pk2(e)), "v"(pk2(o)));
-    return unpk2(r);
+// p = e + i o = (e.x - o.y, e.y + o.x) and m = e - i o = (e.x + o.y, e.y - o.x): one packed add each, the component
+// swap of o and the sign riding along as operand modifiers (written as `e + {-o.y, o.x}` the compiler builds the rotated
+// pair first, one v_xor and one v_mov per butterfly -- a tenth of the instructions of a single-precision transform
+// kernel).  The wait state in front: between a packed instruction and a dependent one the compiler inserts one (s_nop 0)
+// wherever it sees both; it does not look inside an asm statement for the operands' producer, so the statement brings
+// its own (behind the statement the compiler does insert it).
+__device__ __forceinline__ void cbfly_i(float2 e, float2 o, float2& p, float2& m) {
+    f32pair rp, rm;
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"
+        : "=&v"(rp), "=&v"(rm) : "v"(pk2(e)), "v"(pk2(o)));
+    p = unpk2(rp); m = unpk2(rm);
 }
-__device__ __forceinline__ float2 csub_i(float2 e, float2 o) {
-    f32pair r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=&v"(r) : "v"(pk2(e)), "v"(pk2(o)));
-    return unpk2(r);
+template <typename C> __device__ __forceinline__ void cbfly_i(C e, C o, C& p, C& m) {
+    p.x = e.x - o.y; p.y = e.y + o.x;
+    m.x = e.x + o.y; m.y = e.y - o.x;
 }
-template <typename C> __device__ __forceinline__ C cadd_i(C e, C o) { C r; r.x = e.x - o.y; r.y = e.y + o.x; return r; }
-template <typename C> __device__ __forceinline__ C csub_i(C e, C o) { C r; r.x = e.x + o.y; r.y = e.y - o.x; return r; }
 
 // cos/sin(2 pi m / 16), m = 0..7
 __device__ __forceinline__ constexpr double cos16(int m) {
@@ -95,8 +98,8 @@ __device__ __forceinline__ void dft(cx<T> (&a)[R]) {
             constexpr int STEP = 16 / R;
             const int m = k * STEP;  // twiddle W_R^k = exp(SGN * 2 pi i m / 16)
             if (m == 4) {            // o * (SGN * i)
-                a[k] = SGN > 0 ? cadd_i(e[k], o[k]) : csub_i(e[k], o[k]);
-                a[k + H] = SGN > 0 ? csub_i(e[k], o[k]) : cadd_i(e[k], o[k]);
+                if constexpr (SGN > 0) cbfly_i(e[k], o[k], a[k], a[k + H]);
+                else cbfly_i(e[k], o[k], a[k + H], a[k]);
                 continue;
             }
             if (k == 0) {
